@@ -1,0 +1,374 @@
+// api.hip - extern "C" entry points of libgsr_hip.so (declared in include/gsr.h) and host orchestration.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gsr_common.h"
+
+// launchers defined in the kernel files
+void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&,
+                               hipStream_t);
+void gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
+                               const GsrGeomLayout&, const uint32_t*, const float4*, const gsr_grads*, hipStream_t);
+void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
+void gsr_launch_emit(int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, hipStream_t);
+void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, bool, hipStream_t);
+void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
+                           float*, float*, uint32_t*, hipStream_t);
+void gsr_launch_render_bwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*,
+                           const float*, const uint32_t*, const float*, const float*, float4*, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------
+static thread_local char t_err[1024] = "";
+
+void gsr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(t_err, sizeof(t_err), fmt, ap);
+  va_end(ap);
+}
+
+int gsr_check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  gsr_set_error("%s: %s", what, hipGetErrorString(e));
+  return GSR_ERR_HIP;
+}
+
+static int debug_sync(const gsr_settings* s, hipStream_t st, const char* stage) {
+  if (!s->debug) return 0;
+  hipError_t e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) {
+    gsr_set_error("debug: failure after stage '%s': %s", stage, hipGetErrorString(e));
+    return GSR_ERR_HIP;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-kernel profiling (HIP events on the launch stream)
+// ---------------------------------------------------------------------------------------------------
+int g_gsr_profile_on = 0;
+namespace {
+struct Pending { const char* name; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_free_events;
+std::map<std::string, std::pair<double, int64_t>> g_totals;
+std::vector<std::string> g_names_keepalive;
+thread_local Pending t_open = {nullptr, nullptr, nullptr};
+
+hipEvent_t get_event() {
+  if (!g_free_events.empty()) {
+    hipEvent_t e = g_free_events.back();
+    g_free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void collect_locked() {
+  for (auto& p : g_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      auto& t = g_totals[p.name];
+      t.first += ms;
+      t.second += 1;
+    }
+    g_free_events.push_back(p.a);
+    g_free_events.push_back(p.b);
+  }
+  g_pending.clear();
+}
+}  // namespace
+
+void gsr_prof_begin(const char* name, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  t_open.name = name;
+  t_open.a = get_event();
+  t_open.b = get_event();
+  (void)hipEventRecord(t_open.a, st);
+}
+
+void gsr_prof_end(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(t_open.b, st);
+  g_pending.push_back(t_open);
+  if (g_pending.size() > 4096) collect_locked();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pinned read-back slot (one per host thread)
+// ---------------------------------------------------------------------------------------------------
+static uint32_t* pinned_slot() {
+  static thread_local uint32_t* p = nullptr;
+  if (!p) {
+    if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+  }
+  return p;
+}
+
+static int tile_bits(int tiles) {
+  int b = 1;
+  while ((1 << b) < tiles) b++;
+  return b;
+}
+
+static int validate(const gsr_settings* s, const gsr_gaussians* g) {
+  if (!s || !g) { gsr_set_error("null settings/gaussians"); return GSR_ERR_INVALID_ARGUMENT; }
+  if (g->P < 0 || s->image_width <= 0 || s->image_height <= 0) {
+    gsr_set_error("bad sizes P=%d W=%d H=%d", g->P, s->image_width, s->image_height);
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (g->P == 0) return 0;  // nothing to rasterize: background only
+  if ((g->shs == nullptr && g->dc == nullptr) == (g->colors_precomp == nullptr)) {
+    gsr_set_error("Please provide excatly one of either SHs or precomputed colors!");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  const bool sr = g->scales != nullptr || g->rotations != nullptr;
+  if ((sr && g->cov3D_precomp) || (!sr && !g->cov3D_precomp) || (sr && (!g->scales || !g->rotations))) {
+    gsr_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (!g->colors_precomp) {
+    if (s->sh_degree < 0 || s->sh_degree > 3) {
+      gsr_set_error("sh_degree %d unsupported (0..3)", s->sh_degree);
+      return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const int need = (s->sh_degree + 1) * (s->sh_degree + 1);
+    const int have = g->sh_coeffs + (g->dc ? 1 : 0);
+    if (have < need || (need > 1 && !g->shs)) {
+      gsr_set_error("sh_degree %d needs %d coefficients, %d stored", s->sh_degree, need, have);
+      return GSR_ERR_INVALID_ARGUMENT;
+    }
+  }
+  if (s->image_width > 65535 * GSR_TILE || s->image_height > 65535 * GSR_TILE) {
+    gsr_set_error("image too large");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  return 0;
+}
+
+extern "C" {
+
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+const char* gsr_last_error(void) { return t_err; }
+
+size_t gsr_geometry_state_bytes(int32_t P) { return gsr_geom_layout((size_t)(P < 0 ? 0 : P)).total; }
+size_t gsr_image_state_bytes(int32_t W, int32_t H) { return gsr_img_layout((size_t)W * (size_t)H).total; }
+size_t gsr_binning_state_bytes(int32_t P, int32_t W, int32_t H, int64_t R) {
+  (void)P;
+  const size_t tiles = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * (size_t)((H + GSR_TILE - 1) / GSR_TILE);
+  return gsr_bin_layout((size_t)(R < 0 ? 0 : R), tiles).total;
+}
+size_t gsr_backward_scratch_bytes(int32_t P, int64_t R) {
+  (void)P;
+  return gsr_align((size_t)(R < 1 ? 1 : R) * 16 * GSR_IGRAD_F4);
+}
+
+int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
+                            size_t geometry_bytes, int32_t* radii, void* stream) {
+  int rc = validate(s, g);
+  if (rc) return rc;
+  const int P = g->P;
+  if (P == 0) return 0;
+  const GsrGeomLayout L = gsr_geom_layout(P);
+  if (!geometry_state || geometry_bytes < L.total) {
+    gsr_set_error("geometry state too small: %zu < %zu", geometry_bytes, L.total);
+    return GSR_ERR_STATE_TOO_SMALL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* geom = (char*)geometry_state;
+  uint32_t* meta = (uint32_t*)(geom + L.meta);
+  if ((rc = gsr_check(hipMemsetAsync(meta, 0, 64, st), "memset meta"))) return rc;
+
+  gsr_launch_preprocess_fwd(s, g, radii, geom, L, st);
+  if ((rc = debug_sync(s, st, "preprocess"))) return rc;
+
+  // depth order of the Gaussians (stable, so equal depths keep ascending id); 4 passes -> result in (depth_key, order)
+  const int where = gsr_radix_sort_pairs((uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order),
+                                         (uint32_t*)(geom + L.key_tmp), (uint32_t*)(geom + L.val_tmp),
+                                         /*vals_iota=*/true, (size_t)P, 32, (uint32_t*)(geom + L.radix_tmp), st);
+  if (where != 0) { gsr_set_error("internal: depth sort ended in the wrong buffer"); return GSR_ERR_HIP; }
+  if ((rc = debug_sync(s, st, "depth sort"))) return rc;
+
+  // inclusive prefix sum of tiles_touched in depth order
+  gsr_scan_u32((const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.order),
+               (uint32_t*)(geom + L.offsets), (size_t)P, 1, (uint32_t*)(geom + L.scan_tmp), st);
+  if ((rc = debug_sync(s, st, "tile-count scan"))) return rc;
+
+  uint32_t* host = pinned_slot();
+  if (!host) { gsr_set_error("hipHostMalloc failed"); return GSR_ERR_HIP; }
+  if ((rc = gsr_check(hipMemcpyAsync(&host[0], (uint32_t*)(geom + L.offsets) + (P - 1), 4, hipMemcpyDeviceToHost, st),
+                      "read num_rendered")))
+    return rc;
+  if ((rc = gsr_check(hipMemcpyAsync(&host[1], meta + 1, 4, hipMemcpyDeviceToHost, st), "read flags"))) return rc;
+  if ((rc = gsr_check(hipStreamSynchronize(st), "sync after prepare"))) return rc;
+  if (host[1] & 1u) {
+    gsr_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+    return GSR_ERR_PREFILTERED_CULLED;
+  }
+  if (host[0] > 0x7FFFFFFFu) {
+    gsr_set_error("num_rendered %u does not fit 31 bits", host[0]);
+    return GSR_ERR_TOO_MANY_INSTANCES;
+  }
+  return (int64_t)host[0];
+}
+
+int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
+                       size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
+                       float* out_color, float* out_invdepth, int32_t for_backward, void* stream) {
+  int rc = validate(s, g);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int W = s->image_width, H = s->image_height;
+  const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+  const int tiles = gx * gy;
+  const size_t R = (size_t)num_rendered;
+  const GsrGeomLayout GL = gsr_geom_layout(g->P);
+  const GsrBinLayout BL = gsr_bin_layout(R, tiles);
+  const GsrImgLayout IL = gsr_img_layout((size_t)W * H);
+  if (!binning_state || binning_bytes < BL.total || !image_state || image_bytes < IL.total) {
+    gsr_set_error("binning/image state too small: %zu < %zu or %zu < %zu", binning_bytes, BL.total, image_bytes,
+                  IL.total);
+    return GSR_ERR_STATE_TOO_SMALL;
+  }
+  char* geom = (char*)geometry_state;
+  char* bin = (char*)binning_state;
+  char* img = (char*)image_state;
+  if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
+  if (R > 0) {
+    gsr_launch_emit(g->P, gx, geom, GL, bin, BL, st);
+    if ((rc = debug_sync(s, st, "emit instances"))) return rc;
+    const int where = gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a),
+                                           (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.val_b),
+                                           /*vals_iota=*/true, R, tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st);
+    if ((rc = debug_sync(s, st, "tile sort"))) return rc;
+    const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
+    const uint32_t* vs = (const uint32_t*)(bin + (where ? BL.val_b : BL.val_a));
+    gsr_launch_finalize((uint32_t)R, ks, vs, bin, BL, for_backward != 0, st);
+    if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
+  }
+  gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + BL.point_list),
+                        (const float4*)(geom + GL.rec), out_color, out_invdepth, (float*)(img + IL.final_T),
+                        (uint32_t*)(img + IL.n_contrib), st);
+  if ((rc = debug_sync(s, st, "render forward"))) return rc;
+  return gsr_check(hipGetLastError(), "forward launch");
+}
+
+int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,
+                 const void* binning_state, const void* image_state, int64_t num_rendered, const float* dL_dcolor,
+                 const float* dL_dinvdepth, void* scratch, size_t scratch_bytes, const gsr_grads* grads,
+                 void* stream) {
+  int rc = validate(s, g);
+  if (rc) return rc;
+  if (!grads || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacities || !dL_dcolor) {
+    gsr_set_error("backward: missing mandatory gradient buffers");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (g->P == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int W = s->image_width, H = s->image_height;
+  const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+  const int tiles = gx * gy;
+  const size_t R = (size_t)num_rendered;
+  if (scratch_bytes < gsr_backward_scratch_bytes(g->P, num_rendered) || !scratch) {
+    gsr_set_error("backward scratch too small");
+    return GSR_ERR_STATE_TOO_SMALL;
+  }
+  const GsrGeomLayout GL = gsr_geom_layout(g->P);
+  const GsrBinLayout BL = gsr_bin_layout(R, tiles);
+  const GsrImgLayout IL = gsr_img_layout((size_t)W * H);
+  const char* geom = (const char*)geometry_state;
+  const char* bin = (const char*)binning_state;
+  const char* img = (const char*)image_state;
+  float4* igrad = (float4*)scratch;
+  if (R > 0) {
+    gsr_launch_render_bwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + BL.point_list),
+                          (const float4*)(geom + GL.rec), (const float*)(img + IL.final_T),
+                          (const uint32_t*)(img + IL.n_contrib), dL_dcolor, dL_dinvdepth, igrad, st);
+    if ((rc = debug_sync(s, st, "render backward"))) return rc;
+  }
+  gsr_launch_preprocess_bwd(s, g, radii, geom, GL, (const uint32_t*)(bin + BL.pos_of_slot), igrad, grads, st);
+  if ((rc = debug_sync(s, st, "preprocess backward"))) return rc;
+  return gsr_check(hipGetLastError(), "backward launch");
+}
+
+int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream) {
+  if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) {
+    gsr_set_error("mark_visible: bad arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (P == 0) return 0;
+  gsr_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+  return gsr_check(hipGetLastError(), "mark_visible launch");
+}
+
+int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float** rec48,
+                             const uint32_t** depth_keys_sorted, const uint32_t** order, const uint32_t** tiles_touched,
+                             const uint16_t** rect, const uint32_t** offsets) {
+  const GsrGeomLayout L = gsr_geom_layout((size_t)(P < 0 ? 0 : P));
+  const char* geom = (const char*)geometry_state;
+  if (rec48) *rec48 = (const float*)(geom + L.rec);
+  if (depth_keys_sorted) *depth_keys_sorted = (const uint32_t*)(geom + L.depth_key);
+  if (order) *order = (const uint32_t*)(geom + L.order);
+  if (tiles_touched) *tiles_touched = (const uint32_t*)(geom + L.tiles_touched);
+  if (rect) *rect = (const uint16_t*)(geom + L.rect);
+  if (offsets) *offsets = (const uint32_t*)(geom + L.offsets);
+  return 0;
+}
+
+int gsr_debug_binning_views(const void* binning_state, int32_t W, int32_t H, int64_t R, const uint32_t** point_list,
+                            const uint32_t** ranges) {
+  const size_t tiles = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * (size_t)((H + GSR_TILE - 1) / GSR_TILE);
+  const GsrBinLayout BL = gsr_bin_layout((size_t)R, tiles);
+  const char* bin = (const char*)binning_state;
+  if (point_list) *point_list = (const uint32_t*)(bin + BL.point_list);
+  if (ranges) *ranges = (const uint32_t*)(bin + BL.ranges);
+  return 0;
+}
+
+int gsr_debug_image_views(const void* image_state, int32_t W, int32_t H, const float** final_T,
+                          const uint32_t** n_contrib) {
+  const GsrImgLayout IL = gsr_img_layout((size_t)W * H);
+  const char* img = (const char*)image_state;
+  if (final_T) *final_T = (const float*)(img + IL.final_T);
+  if (n_contrib) *n_contrib = (const uint32_t*)(img + IL.n_contrib);
+  return 0;
+}
+
+void gsr_profile_enable(int32_t on) { g_gsr_profile_on = on ? 1 : 0; }
+
+void gsr_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  collect_locked();
+  g_totals.clear();
+}
+
+int32_t gsr_profile_read(const char** names, double* total_ms, int64_t* calls, int32_t max) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  collect_locked();
+  g_names_keepalive.clear();
+  for (auto& kv : g_totals) g_names_keepalive.push_back(kv.first);
+  int32_t i = 0;
+  for (auto& kv : g_totals) {
+    if (i < max) {
+      if (names) names[i] = g_names_keepalive[i].c_str();
+      if (total_ms) total_ms[i] = kv.second.first;
+      if (calls) calls[i] = kv.second.second;
+    }
+    i++;
+  }
+  return i;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// binning.hip - instance emission and tile ranges (K3 / K5 of SURVEY.md 2.3), MI355X design.
+//
+// The published rasterizer sorts R 64-bit (tile<<32 | depth) keys in one global radix sort (6 passes over
+// R pairs).  Here the same total order (tile, depth bits, Gaussian id) is produced with far less traffic:
+//   1. Gaussians are depth-sorted ONCE (32-bit keys, P elements)            [api.hip -> gsr_radix_sort_pairs]
+//   2. instances are emitted in that depth order                             [k_emit_instances]
+//   3. a STABLE sort on the tile id alone (<= 15 bits at 4K: 2 passes)       [gsr_radix_sort_pairs]
+// Stability of step 3 keeps (depth, id) order inside each tile, so the per-tile lists are identical to the
+// published ordering (ties on equal depth bits broken by ascending Gaussian id because step 1 is stable on
+// an id-ordered input).
+#include "gsr_common.h"
+
+// one thread per depth-sorted position j
+__global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const uint32_t* __restrict__ order,
+                                                        const uint32_t* __restrict__ offsets_incl,
+                                                        const uint32_t* __restrict__ tiles_touched,
+                                                        const ushort4* __restrict__ rect, uint32_t* __restrict__ tile_key,
+                                                        uint32_t* __restrict__ gauss_of_slot,
+                                                        uint32_t* __restrict__ slot_start) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= P) return;
+  const uint32_t g = order[j];
+  const uint32_t n = tiles_touched[g];
+  if (n == 0) return;  // culled Gaussians sort to the end (key 0xFFFFFFFF) and emit nothing
+  uint32_t off = offsets_incl[j] - n;
+  slot_start[g] = off;
+  const ushort4 r = rect[g];
+  for (int y = r.y; y < r.w; y++) {
+    for (int x = r.x; x < r.z; x++) {
+      tile_key[off] = (uint32_t)(y * grid_x + x);
+      gauss_of_slot[off] = g;
+      off++;
+    }
+  }
+}
+
+// one thread per sorted instance position: tile ranges + Gaussian id list + inverse permutation
+__global__ __launch_bounds__(256) void k_finalize_bins(uint32_t R, const uint32_t* __restrict__ tile_sorted,
+                                                       const uint32_t* __restrict__ slot_sorted,
+                                                       const uint32_t* __restrict__ gauss_of_slot,
+                                                       uint32_t* __restrict__ point_list, uint32_t* __restrict__ pos_of_slot,
+                                                       uint2* __restrict__ ranges) {
+  const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= R) return;
+  const uint32_t e = slot_sorted[pos];
+  point_list[pos] = gauss_of_slot[e];
+  if (pos_of_slot) pos_of_slot[e] = pos;
+  const uint32_t t = tile_sorted[pos];
+  if (pos == 0) {
+    ranges[t].x = 0;
+  } else {
+    const uint32_t prev = tile_sorted[pos - 1];
+    if (prev != t) {
+      ranges[prev].y = pos;
+      ranges[t].x = pos;
+    }
+  }
+  if (pos == R - 1) ranges[t].y = R;
+}
+
+void gsr_launch_emit(int P, int grid_x, const char* geom, const GsrGeomLayout& GL, char* bin, const GsrBinLayout& BL,
+                     hipStream_t st) {
+  GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
+             (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
+             (const uint32_t*)(geom + GL.tiles_touched), (const ushort4*)(geom + GL.rect),
+             (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start));
+}
+
+void gsr_launch_finalize(uint32_t R, const uint32_t* tile_sorted, const uint32_t* slot_sorted, char* bin,
+                         const GsrBinLayout& BL, bool for_backward, hipStream_t st) {
+  GSR_LAUNCH("finalize_bins", k_finalize_bins, dim3((R + 255) / 256), dim3(256), 0, st, R, tile_sorted, slot_sorted,
+             (const uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(bin + BL.point_list),
+             for_backward ? (uint32_t*)(bin + BL.pos_of_slot) : (uint32_t*)nullptr, (uint2*)(bin + BL.ranges));
+}

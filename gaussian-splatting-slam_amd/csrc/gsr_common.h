@@ -1,0 +1,182 @@
+// gsr_common.h - shared host/device definitions for libgsr_hip (gfx950 only, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/gsr.h"
+
+#define GSR_TILE 16                 // 16x16 pixel tiles
+#define GSR_TILE_PIX 256
+#define GSR_WAVE 64
+#define GSR_REC_F4 3                // packed splat record = 3 float4 = 48 B
+#define GSR_IGRAD_F4 3              // per-instance gradient record = 3 float4 (10 used)
+
+// -------------------------------------------------------------------------------------------------
+// Packed per-Gaussian splat record written by preprocess and staged through LDS by the render kernels:
+//   r0 = (mean2D.x, mean2D.y, conic.A, conic.B)
+//   r1 = (conic.C, opacity*aa, rgb.r, rgb.g)
+//   r2 = (rgb.b, 1/depth, depth, unused)
+// One 48-B gather per (tile, instance) instead of four separate arrays.
+// -------------------------------------------------------------------------------------------------
+
+struct GsrGeomLayout {
+  // all offsets in bytes from the start of the geometry state; every array 256-B aligned
+  size_t rec;            // float4[3P]
+  size_t depth_key;      // u32[P]   fp32 depth bits, 0xFFFFFFFF when culled   (sort key, buffer A)
+  size_t order;          // u32[P]   Gaussian ids (sort value, buffer A) -> depth-sorted ids
+  size_t key_tmp;        // u32[P]   sort ping-pong B
+  size_t val_tmp;        // u32[P]   sort ping-pong B
+  size_t tiles_touched;  // u32[P]
+  size_t rect;           // ushort4[P] tile rect (min.x, min.y, max.x, max.y)
+  size_t offsets;        // u32[P]   inclusive scan of tiles_touched in depth order
+  size_t slot_start;     // u32[P]   first emission slot of Gaussian g
+  size_t clamped;        // u8[P]    bit c set: colour channel c clamped at 0
+  size_t scan_tmp;       // u32[...] block sums for the scans
+  size_t radix_tmp;      // u32[...] digit-count tables
+  size_t meta;           // u32[16]  [0]=num_rendered [1]=error flags
+  size_t total;
+};
+
+struct GsrBinLayout {
+  size_t key_a, key_b;   // u32[R] tile ids (ping-pong)
+  size_t val_a, val_b;   // u32[R] emission slots (ping-pong)
+  size_t gauss_of_slot;  // u32[R]
+  size_t point_list;     // u32[R] Gaussian ids sorted by (tile, depth, id)
+  size_t pos_of_slot;    // u32[R] final position of each emission slot (backward)
+  size_t ranges;         // uint2[tiles]
+  size_t scan_tmp;
+  size_t radix_tmp;
+  size_t total;
+};
+
+struct GsrImgLayout {
+  size_t final_T;        // f32[N]
+  size_t n_contrib;      // u32[N]
+  size_t total;
+};
+
+static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// sort/scan tuning shared by the sizing code and the kernels
+#define GSR_SCAN_ITEMS 8                         // per thread
+#define GSR_SCAN_CHUNK (256 * GSR_SCAN_ITEMS)    // per block
+#define GSR_RADIX_BITS 8
+#define GSR_RADIX_SIZE 256
+#define GSR_RADIX_SUBTILES 16
+#define GSR_RADIX_CHUNK (256 * GSR_RADIX_SUBTILES)
+
+static inline size_t gsr_scan_tmp_elems(size_t n) {
+  // block sums for level 0, level 1, ... (recursive)
+  size_t tot = 0;
+  while (n > 1) {
+    n = (n + GSR_SCAN_CHUNK - 1) / GSR_SCAN_CHUNK;
+    tot += gsr_align(n * 4) / 4;
+    if (n == 1) break;
+  }
+  return tot + 64;
+}
+static inline size_t gsr_radix_blocks(size_t n) { return (n + GSR_RADIX_CHUNK - 1) / GSR_RADIX_CHUNK; }
+static inline size_t gsr_radix_tmp_elems(size_t n) {
+  size_t tab = GSR_RADIX_SIZE * (gsr_radix_blocks(n) + 1);
+  return gsr_align(tab * 4) / 4 + gsr_scan_tmp_elems(tab);
+}
+
+static inline GsrGeomLayout gsr_geom_layout(size_t P) {
+  GsrGeomLayout L;
+  size_t o = 0;
+  if (P == 0) P = 1;
+  L.rec = o;           o += gsr_align(P * 48);
+  L.depth_key = o;     o += gsr_align(P * 4);
+  L.order = o;         o += gsr_align(P * 4);
+  L.key_tmp = o;       o += gsr_align(P * 4);
+  L.val_tmp = o;       o += gsr_align(P * 4);
+  L.tiles_touched = o; o += gsr_align(P * 4);
+  L.rect = o;          o += gsr_align(P * 8);
+  L.offsets = o;       o += gsr_align(P * 4);
+  L.slot_start = o;    o += gsr_align(P * 4);
+  L.clamped = o;       o += gsr_align(P);
+  L.scan_tmp = o;      o += gsr_align(gsr_scan_tmp_elems(P) * 4);
+  L.radix_tmp = o;     o += gsr_align(gsr_radix_tmp_elems(P) * 4);
+  L.meta = o;          o += 256;
+  L.total = o;
+  return L;
+}
+
+static inline GsrBinLayout gsr_bin_layout(size_t R, size_t tiles) {
+  GsrBinLayout L;
+  size_t o = 0;
+  if (R == 0) R = 1;
+  L.key_a = o;         o += gsr_align(R * 4);
+  L.key_b = o;         o += gsr_align(R * 4);
+  L.val_a = o;         o += gsr_align(R * 4);
+  L.val_b = o;         o += gsr_align(R * 4);
+  L.gauss_of_slot = o; o += gsr_align(R * 4);
+  L.point_list = o;    o += gsr_align(R * 4);
+  L.pos_of_slot = o;   o += gsr_align(R * 4);
+  L.ranges = o;        o += gsr_align(tiles * 8);
+  L.scan_tmp = o;      o += gsr_align(gsr_scan_tmp_elems(R) * 4);
+  L.radix_tmp = o;     o += gsr_align(gsr_radix_tmp_elems(R) * 4);
+  L.total = o;
+  return L;
+}
+
+static inline GsrImgLayout gsr_img_layout(size_t N) {
+  GsrImgLayout L;
+  size_t o = 0;
+  L.final_T = o;   o += gsr_align(N * 4);
+  L.n_contrib = o; o += gsr_align(N * 4);
+  L.total = o;
+  return L;
+}
+
+// -------------------------------------------------------------------------------------------------
+// host-side launch helpers (api.hip owns the definitions)
+// -------------------------------------------------------------------------------------------------
+void gsr_set_error(const char* fmt, ...);
+int gsr_check(hipError_t e, const char* what);
+void gsr_prof_begin(const char* name, hipStream_t st);
+void gsr_prof_end(hipStream_t st);
+extern int g_gsr_profile_on;
+
+#define GSR_LAUNCH(name, kern, grid, block, shmem, st, ...)                    \
+  do {                                                                         \
+    if (g_gsr_profile_on) gsr_prof_begin(name, st);                            \
+    hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);             \
+    if (g_gsr_profile_on) gsr_prof_end(st);                                    \
+  } while (0)
+
+// sort_scan.hip
+// Exclusive (inclusive=0) or inclusive scan of n u32 values: out[i] = scan(src[idx ? idx[i] : i]).
+void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_t n, int inclusive,
+                  uint32_t* tmp, hipStream_t st);
+// Stable LSD radix sort of (key,value) pairs on key bits [0, bits).  vals_in == nullptr means value = index.
+// Buffers ping-pong between (k0,v0) and (k1,v1); returns 0 if the result is in (k0,v0), 1 if in (k1,v1).
+int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
+                         int bits, uint32_t* tmp, hipStream_t st);
+
+// -------------------------------------------------------------------------------------------------
+// device helpers
+// -------------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int gsr_lane() { return threadIdx.x & 63; }
+
+// add with a DPP-shifted copy of itself (old = 0 for lanes without a source)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float gsr_dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return v + __int_as_float(t);
+}
+// Full-wave (64-lane) sum; the total is valid in lane 63 only.  gfx9 DPP scan: row_shr 1,2,4,8 then
+// row_bcast15 / row_bcast31.
+__device__ __forceinline__ float gsr_wave_sum_to_lane63(float v) {
+  v = gsr_dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
+  v = gsr_dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
+  v = gsr_dpp_add<0x114, 0xf, 0xf>(v);  // row_shr:4
+  v = gsr_dpp_add<0x118, 0xf, 0xf>(v);  // row_shr:8
+  v = gsr_dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 -> rows 1,3
+  v = gsr_dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+#endif

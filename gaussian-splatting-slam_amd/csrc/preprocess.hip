@@ -1,0 +1,561 @@
+// preprocess.hip - per-Gaussian stages of the rasterizer (gfx950).
+//
+//   k_preprocess_fwd : K1 of SURVEY.md 2.3 (near cull, projection, EWA covariance, dilation / AA,
+//                      conic, radius, tile rect, SH -> RGB) - writes the packed 48-B splat record.
+//   k_preprocess_bwd : K8 + K9 fused, preceded by a deterministic per-Gaussian gather-sum of the
+//                      per-instance gradient records written by the render backward (no float atomics:
+//                      MI355X global float atomics hit 64 different rows at ~0.08 TB/s, plain stores +
+//                      a gather pass run at HBM rate and make the gradients bitwise reproducible).
+//   k_mark_visible   : K10.
+//
+// Semantics follow SURVEY.md Appendix A (the published algorithm of
+// graphdeco-inria/diff-gaussian-rasterization@9c5c2028, absent from the reference tree) and the boundary
+// contract of reference gaussian_renderer/__init__.py:18-121.  SH basis / constants: reference
+// utils/sh_utils.py:26-100.  Quaternion -> R and Sigma packing: reference utils/general_utils.py:64-110.
+#include "gsr_common.h"
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+struct PreView {
+  float V[16];   // viewmatrix, flat (column-major W2C)
+  float PV[16];  // projmatrix, flat
+  float cam[3];
+};
+
+__device__ __forceinline__ void load_view(const float* vm, const float* pm, const float* campos, PreView& v) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    v.V[i] = vm[i];
+    v.PV[i] = pm[i];
+  }
+  v.cam[0] = campos[0];
+  v.cam[1] = campos[1];
+  v.cam[2] = campos[2];
+}
+
+// Sigma (6-vector) from scale / rotation (A.2): Sigma = R diag(mod*s)^2 R^T
+__device__ __forceinline__ void cov3d_from_sr(const float* s3, const float* q4, float mod, float* cov6,
+                                              float* Rout /*9, row-major, may be null*/) {
+  const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
+  float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z),       2.f * (x * z + r * y),
+                2.f * (x * y + r * z),       1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                2.f * (x * z - r * y),       2.f * (y * z + r * x),       1.f - 2.f * (x * x + y * y)};
+  const float sx = mod * s3[0], sy = mod * s3[1], sz = mod * s3[2];
+  float L[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    L[3 * i + 0] = R[3 * i + 0] * sx;
+    L[3 * i + 1] = R[3 * i + 1] * sy;
+    L[3 * i + 2] = R[3 * i + 2] * sz;
+  }
+  cov6[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+  cov6[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+  cov6[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
+  cov6[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+  cov6[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
+  cov6[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+  if (Rout) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rout[i] = R[i];
+  }
+}
+
+// EWA projection pieces shared by forward and backward.
+struct Ewa {
+  float tx, ty, tz;   // (clamped) view-space mean
+  bool in_x, in_y;    // clamp masks
+  float m0[3], m1[3]; // rows of M = J W
+  float a0, b, c0;    // cov2D before dilation
+};
+
+__device__ __forceinline__ void ewa_project(const float t[3], const PreView& v, const float* cov6, float fx,
+                                            float fy, float tanfovx, float tanfovy, Ewa& e) {
+  const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+  const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+  e.in_x = !(txtz < -limx || txtz > limx);
+  e.in_y = !(tytz < -limy || tytz > limy);
+  e.tx = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+  e.ty = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+  e.tz = t[2];
+  const float j00 = fx / e.tz, j02 = -(fx * e.tx) / (e.tz * e.tz);
+  const float j11 = fy / e.tz, j12 = -(fy * e.ty) / (e.tz * e.tz);
+  // W row k = (V[k], V[4+k], V[8+k])
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    e.m0[j] = j00 * v.V[4 * j + 0] + j02 * v.V[4 * j + 2];
+    e.m1[j] = j11 * v.V[4 * j + 1] + j12 * v.V[4 * j + 2];
+  }
+  // Sigma m
+  const float s0x = cov6[0] * e.m0[0] + cov6[1] * e.m0[1] + cov6[2] * e.m0[2];
+  const float s0y = cov6[1] * e.m0[0] + cov6[3] * e.m0[1] + cov6[4] * e.m0[2];
+  const float s0z = cov6[2] * e.m0[0] + cov6[4] * e.m0[1] + cov6[5] * e.m0[2];
+  const float s1x = cov6[0] * e.m1[0] + cov6[1] * e.m1[1] + cov6[2] * e.m1[2];
+  const float s1y = cov6[1] * e.m1[0] + cov6[3] * e.m1[1] + cov6[4] * e.m1[2];
+  const float s1z = cov6[2] * e.m1[0] + cov6[4] * e.m1[1] + cov6[5] * e.m1[2];
+  e.a0 = e.m0[0] * s0x + e.m0[1] * s0y + e.m0[2] * s0z;
+  e.b = e.m0[0] * s1x + e.m0[1] * s1y + e.m0[2] * s1z;
+  e.c0 = e.m1[0] * s1x + e.m1[1] * s1y + e.m1[2] * s1z;
+}
+
+__device__ __forceinline__ float sh_coef(const float* dc, const float* shs, int stride, int idx, int k, int c) {
+  // coefficient k of channel c of Gaussian idx; with `dc`, band 0 lives there and shs holds k-1
+  if (dc) return (k == 0) ? dc[3 * (size_t)idx + c] : shs[((size_t)idx * stride + (k - 1)) * 3 + c];
+  return shs[((size_t)idx * stride + k) * 3 + c];
+}
+
+__device__ __forceinline__ void sh_basis_eval(int deg, float x, float y, float z, float* b /*16*/) {
+  b[0] = SH_C0;
+  if (deg > 0) {
+    b[1] = -SH_C1 * y;
+    b[2] = SH_C1 * z;
+    b[3] = -SH_C1 * x;
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      b[4] = SH_C2[0] * xy;
+      b[5] = SH_C2[1] * yz;
+      b[6] = SH_C2[2] * (2.f * zz - xx - yy);
+      b[7] = SH_C2[3] * xz;
+      b[8] = SH_C2[4] * (xx - yy);
+      if (deg > 2) {
+        b[9] = SH_C3[0] * y * (3.f * xx - yy);
+        b[10] = SH_C3[1] * xy * z;
+        b[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+        b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+        b[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+        b[14] = SH_C3[5] * z * (xx - yy);
+        b[15] = SH_C3[6] * x * (xx - 3.f * yy);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1 forward
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_preprocess_fwd(
+    int P, int deg, int sh_stride, const float* __restrict__ means3D, const float* __restrict__ dc,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    float scale_modifier, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+    const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy, int prefiltered, int antialiasing,
+    int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
+    uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
+    uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  PreView v;
+  load_view(viewmatrix, projmatrix, campos, v);
+
+  // defaults for a culled Gaussian
+  int32_t out_radius = 0;
+  uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu;
+
+  const float p[3] = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+  float t[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) t[i] = v.V[i] * p[0] + v.V[4 + i] * p[1] + v.V[8 + i] * p[2] + v.V[12 + i];
+
+  if (t[2] > 0.2f) {  // A.1 near-plane cull only
+    float hom[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) hom[i] = v.PV[i] * p[0] + v.PV[4 + i] * p[1] + v.PV[8 + i] * p[2] + v.PV[12 + i];
+    const float pw = 1.0f / (hom[3] + 0.0000001f);
+    const float ndcx = hom[0] * pw, ndcy = hom[1] * pw;
+
+    float cov6[6];
+    if (cov3D_precomp) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) cov6[i] = cov3D_precomp[6 * (size_t)idx + i];
+    } else {
+      cov3d_from_sr(scales + 3 * (size_t)idx, rotations + 4 * (size_t)idx, scale_modifier, cov6, nullptr);
+    }
+    const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
+    Ewa e;
+    ewa_project(t, v, cov6, fx, fy, tanfovx, tanfovy, e);
+
+    // A.3 dilation / AA
+    const float det0 = e.a0 * e.c0 - e.b * e.b;
+    const float a = e.a0 + 0.3f, c = e.c0 + 0.3f, b = e.b;
+    const float det = a * c - b * b;
+    float h = 1.0f;
+    if (antialiasing) h = sqrtf(fmaxf(0.000025f, det0 / det));
+    if (det != 0.0f) {
+      const float det_inv = 1.0f / det;
+      const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
+      // A.4 extent
+      const float mid = 0.5f * (a + c);
+      const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float lam = fmaxf(mid + root, mid - root);
+      const float radius = ceilf(3.0f * sqrtf(lam));
+      const float px = ((ndcx + 1.0f) * W - 1.0f) * 0.5f;
+      const float py = ((ndcy + 1.0f) * H - 1.0f) * 0.5f;
+      const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+      // C-style truncation then clamp; guard the float->int conversion against huge values
+      const float lim = 1.0e9f;
+      const int x0 = min(gx, max(0, (int)fminf(lim, fmaxf(-lim, (px - radius) / GSR_TILE))));
+      const int y0 = min(gy, max(0, (int)fminf(lim, fmaxf(-lim, (py - radius) / GSR_TILE))));
+      const int x1 = min(gx, max(0, (int)fminf(lim, fmaxf(-lim, (px + radius + (GSR_TILE - 1)) / GSR_TILE))));
+      const int y1 = min(gy, max(0, (int)fminf(lim, fmaxf(-lim, (py + radius + (GSR_TILE - 1)) / GSR_TILE))));
+      const int area = (x1 - x0) * (y1 - y0);
+      if (area > 0) {
+        float rgb[3];
+        uint8_t cl = 0;
+        if (colors_precomp) {
+          rgb[0] = colors_precomp[3 * (size_t)idx];
+          rgb[1] = colors_precomp[3 * (size_t)idx + 1];
+          rgb[2] = colors_precomp[3 * (size_t)idx + 2];
+        } else {
+          float dx = p[0] - v.cam[0], dy = p[1] - v.cam[1], dz = p[2] - v.cam[2];
+          const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+          dx *= inv; dy *= inv; dz *= inv;
+          float bs[16];
+          sh_basis_eval(deg, dx, dy, dz, bs);
+          const int K = (deg + 1) * (deg + 1);
+          rgb[0] = rgb[1] = rgb[2] = 0.f;
+          for (int k = 0; k < K; k++) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) rgb[ch] += bs[k] * sh_coef(dc, shs, sh_stride, idx, k, ch);
+          }
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) {
+            rgb[ch] += 0.5f;
+            if (rgb[ch] < 0.f) { cl |= (1u << ch); rgb[ch] = 0.f; }
+          }
+        }
+        const float op = opacities[idx] * h;
+        rec[3 * (size_t)idx + 0] = make_float4(px, py, cA, cB);
+        rec[3 * (size_t)idx + 1] = make_float4(cC, op, rgb[0], rgb[1]);
+        rec[3 * (size_t)idx + 2] = make_float4(rgb[2], 1.0f / t[2], t[2], 0.f);
+        rect[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+        clamped[idx] = cl;
+        out_radius = (int32_t)radius;
+        out_tiles = (uint32_t)area;
+        out_key = __float_as_uint(t[2]);
+      }
+    }
+  } else if (prefiltered) {
+    meta[1] = 1u;  // prefiltered point failed the near-plane test (hard error upstream)
+  }
+  radii[idx] = out_radius;
+  tiles_touched[idx] = out_tiles;
+  depth_key[idx] = out_key;
+  order[idx] = (uint32_t)idx;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K8 + K9 backward, fused with the per-Gaussian gather of per-instance gradients.
+// One thread per Gaussian index (all per-Gaussian arrays coalesced).
+// igrad record (render backward): (d_mx_ndc, d_my_ndc, dA, dB) (dC, d_opacity_eff, d_r, d_g) (d_b, d_invdepth, -, -)
+// where dB is the true derivative wrt conic.B (power = -0.5(A dx^2 + C dy^2) - B dx dy).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_preprocess_bwd(
+    int P, int deg, int sh_stride, const float* __restrict__ means3D, const float* __restrict__ dc,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    float scale_modifier, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+    const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy, int antialiasing,
+    const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const uint32_t* __restrict__ tiles_touched,
+    const uint32_t* __restrict__ slot_start, const uint32_t* __restrict__ pos_of_slot,
+    const float4* __restrict__ igrad, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+    float* __restrict__ dL_ddc, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
+    float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
+    float* __restrict__ dL_dcov3D) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const int K = (deg + 1) * (deg + 1);
+  const bool visible = radii[idx] > 0;
+
+  float g_mean[3] = {0.f, 0.f, 0.f};
+  float g_m2d[2] = {0.f, 0.f};
+  float g_opac = 0.f;
+  float g_cov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float g_col[3] = {0.f, 0.f, 0.f};
+  float g_scale[3] = {0.f, 0.f, 0.f};
+  float g_rot[4] = {0.f, 0.f, 0.f, 0.f};
+  float bs[16];
+  bool have_sh = false;
+
+  if (visible) {
+    // ---- deterministic gather-sum over this Gaussian's instances (slot order) ----
+    float acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) acc[i] = 0.f;
+    const uint32_t s0 = slot_start[idx], n = tiles_touched[idx];
+    for (uint32_t e = 0; e < n; e++) {
+      const size_t pos = pos_of_slot[s0 + e];
+      const float4 r0 = igrad[3 * pos + 0], r1 = igrad[3 * pos + 1], r2 = igrad[3 * pos + 2];
+      acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
+      acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
+      acc[8] += r2.x; acc[9] += r2.y;
+    }
+    g_m2d[0] = acc[0];
+    g_m2d[1] = acc[1];
+    const float gA = acc[2], gB = acc[3], gC = acc[4], g_op_eff = acc[5];
+    float g_rgb[3] = {acc[6], acc[7], acc[8]};
+    const float g_invd = acc[9];
+
+    PreView v;
+    load_view(viewmatrix, projmatrix, campos, v);
+    const float p[3] = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+    float t[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = v.V[i] * p[0] + v.V[4 + i] * p[1] + v.V[8 + i] * p[2] + v.V[12 + i];
+
+    // ---- colour: SH backward (A.7 iv) or pass-through ----
+    if (colors_precomp) {
+      g_col[0] = g_rgb[0]; g_col[1] = g_rgb[1]; g_col[2] = g_rgb[2];
+    } else {
+      const uint8_t cl = clamped[idx];
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++)
+        if (cl & (1u << ch)) g_rgb[ch] = 0.f;
+      float vx = p[0] - v.cam[0], vy = p[1] - v.cam[1], vz = p[2] - v.cam[2];
+      const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+      const float x = vx * inv, y = vy * inv, z = vz * inv;
+      sh_basis_eval(deg, x, y, z, bs);
+      have_sh = true;
+      // direction derivative: g_dir = sum_k dbasis_k/ddir * (sh_k . g_rgb)
+      float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+      if (deg > 0) {
+        float q[16];
+        for (int k = 1; k < K; k++) {
+          q[k] = sh_coef(dc, shs, sh_stride, idx, k, 0) * g_rgb[0] + sh_coef(dc, shs, sh_stride, idx, k, 1) * g_rgb[1] +
+                 sh_coef(dc, shs, sh_stride, idx, k, 2) * g_rgb[2];
+        }
+        gdx += -SH_C1 * q[3];
+        gdy += -SH_C1 * q[1];
+        gdz += SH_C1 * q[2];
+        if (deg > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          gdx += SH_C2[0] * y * q[4] + SH_C2[2] * (-2.f * x) * q[6] + SH_C2[3] * z * q[7] + SH_C2[4] * 2.f * x * q[8];
+          gdy += SH_C2[0] * x * q[4] + SH_C2[1] * z * q[5] + SH_C2[2] * (-2.f * y) * q[6] + SH_C2[4] * (-2.f * y) * q[8];
+          gdz += SH_C2[1] * y * q[5] + SH_C2[2] * 4.f * z * q[6] + SH_C2[3] * x * q[7];
+          if (deg > 2) {
+            gdx += SH_C3[0] * 6.f * xy * q[9] + SH_C3[1] * yz * q[10] + SH_C3[2] * (-2.f * xy) * q[11] +
+                   SH_C3[3] * (-6.f * xz) * q[12] + SH_C3[4] * (4.f * zz - 3.f * xx - yy) * q[13] +
+                   SH_C3[5] * 2.f * xz * q[14] + SH_C3[6] * (3.f * xx - 3.f * yy) * q[15];
+            gdy += SH_C3[0] * (3.f * xx - 3.f * yy) * q[9] + SH_C3[1] * xz * q[10] +
+                   SH_C3[2] * (4.f * zz - xx - 3.f * yy) * q[11] + SH_C3[3] * (-6.f * yz) * q[12] +
+                   SH_C3[4] * (-2.f * xy) * q[13] + SH_C3[5] * (-2.f * yz) * q[14] + SH_C3[6] * (-6.f * xy) * q[15];
+            gdz += SH_C3[1] * xy * q[10] + SH_C3[2] * 8.f * yz * q[11] +
+                   SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy) * q[12] + SH_C3[4] * 8.f * xz * q[13] +
+                   SH_C3[5] * (xx - yy) * q[14];
+          }
+        }
+        // through dir = v/|v|
+        const float dot = x * gdx + y * gdy + z * gdz;
+        g_mean[0] += (gdx - x * dot) * inv;
+        g_mean[1] += (gdy - y * dot) * inv;
+        g_mean[2] += (gdz - z * dot) * inv;
+      }
+      g_col[0] = g_rgb[0]; g_col[1] = g_rgb[1]; g_col[2] = g_rgb[2];  // masked dL/drgb, used for dL/dsh below
+    }
+
+    // ---- covariance chain (A.7 i, ii) ----
+    float cov6[6];
+    float R[9];
+    if (cov3D_precomp) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) cov6[i] = cov3D_precomp[6 * (size_t)idx + i];
+    } else {
+      cov3d_from_sr(scales + 3 * (size_t)idx, rotations + 4 * (size_t)idx, scale_modifier, cov6, R);
+    }
+    const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
+    Ewa e;
+    ewa_project(t, v, cov6, fx, fy, tanfovx, tanfovy, e);
+    const float a = e.a0 + 0.3f, c = e.c0 + 0.3f, b = e.b;
+    const float det = a * c - b * b;
+    const float det2inv = 1.0f / (det * det + 0.0000001f);
+    float g_a = det2inv * (-c * c * gA + b * c * gB - b * b * gC);
+    float g_c = det2inv * (-b * b * gA + a * b * gB - a * a * gC);
+    float g_b = det2inv * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
+    const float opac = opacities[idx];
+    if (antialiasing) {
+      const float det0 = e.a0 * e.c0 - b * b;
+      const float f = det0 / det;
+      const float h = sqrtf(fmaxf(0.000025f, f));
+      g_opac = g_op_eff * h;
+      if (f > 0.000025f) {
+        const float g_f = (g_op_eff * opac) / (2.f * h);
+        const float di = 1.0f / (det * det);
+        g_a += g_f * (e.c0 * det - det0 * c) * di;
+        g_c += g_f * (e.a0 * det - det0 * a) * di;
+        g_b += g_f * (2.f * b * (det0 - det)) * di;
+      }
+    } else {
+      g_opac = g_op_eff;
+    }
+    // cov2D -> Sigma (6-vector; off-diagonals appear twice)
+    const float* m0 = e.m0;
+    const float* m1 = e.m1;
+    g_cov6[0] = g_a * m0[0] * m0[0] + g_b * m0[0] * m1[0] + g_c * m1[0] * m1[0];
+    g_cov6[3] = g_a * m0[1] * m0[1] + g_b * m0[1] * m1[1] + g_c * m1[1] * m1[1];
+    g_cov6[5] = g_a * m0[2] * m0[2] + g_b * m0[2] * m1[2] + g_c * m1[2] * m1[2];
+    g_cov6[1] = 2.f * g_a * m0[0] * m0[1] + g_b * (m0[0] * m1[1] + m0[1] * m1[0]) + 2.f * g_c * m1[0] * m1[1];
+    g_cov6[2] = 2.f * g_a * m0[0] * m0[2] + g_b * (m0[0] * m1[2] + m0[2] * m1[0]) + 2.f * g_c * m1[0] * m1[2];
+    g_cov6[4] = 2.f * g_a * m0[1] * m0[2] + g_b * (m0[1] * m1[2] + m0[2] * m1[1]) + 2.f * g_c * m1[1] * m1[2];
+    // cov2D -> M rows
+    float Sm0[3], Sm1[3];
+    Sm0[0] = cov6[0] * m0[0] + cov6[1] * m0[1] + cov6[2] * m0[2];
+    Sm0[1] = cov6[1] * m0[0] + cov6[3] * m0[1] + cov6[4] * m0[2];
+    Sm0[2] = cov6[2] * m0[0] + cov6[4] * m0[1] + cov6[5] * m0[2];
+    Sm1[0] = cov6[0] * m1[0] + cov6[1] * m1[1] + cov6[2] * m1[2];
+    Sm1[1] = cov6[1] * m1[0] + cov6[3] * m1[1] + cov6[4] * m1[2];
+    Sm1[2] = cov6[2] * m1[0] + cov6[4] * m1[1] + cov6[5] * m1[2];
+    float gm0[3], gm1[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      gm0[j] = 2.f * g_a * Sm0[j] + g_b * Sm1[j];
+      gm1[j] = 2.f * g_c * Sm1[j] + g_b * Sm0[j];
+    }
+    // M -> J (W row k = (V[k], V[4+k], V[8+k]))
+    float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      gJ00 += gm0[j] * v.V[4 * j + 0];
+      gJ02 += gm0[j] * v.V[4 * j + 2];
+      gJ11 += gm1[j] * v.V[4 * j + 1];
+      gJ12 += gm1[j] * v.V[4 * j + 2];
+    }
+    const float tz1 = 1.0f / e.tz, tz2 = tz1 * tz1, tz3 = tz2 * tz1;
+    float g_t[3];
+    g_t[0] = e.in_x ? (-fx * tz2 * gJ02) : 0.f;
+    g_t[1] = e.in_y ? (-fy * tz2 * gJ12) : 0.f;
+    g_t[2] = -fx * tz2 * gJ00 - fy * tz2 * gJ11 + 2.f * fx * e.tx * tz3 * gJ02 + 2.f * fy * e.ty * tz3 * gJ12;
+    // inverse depth output: invd = 1/t.z
+    g_t[2] += -g_invd * tz2;
+    // t = V p
+#pragma unroll
+    for (int j = 0; j < 3; j++) g_mean[j] += v.V[4 * j + 0] * g_t[0] + v.V[4 * j + 1] * g_t[1] + v.V[4 * j + 2] * g_t[2];
+
+    // ---- mean2D (NDC) -> mean3D (A.7 iii) ----
+    {
+      float hom[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) hom[i] = v.PV[i] * p[0] + v.PV[4 + i] * p[1] + v.PV[8 + i] * p[2] + v.PV[12 + i];
+      const float pw = 1.0f / (hom[3] + 0.0000001f);
+      const float mul1 = hom[0] * pw * pw, mul2 = hom[1] * pw * pw;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        g_mean[j] += (v.PV[4 * j + 0] * pw - v.PV[4 * j + 3] * mul1) * g_m2d[0] +
+                     (v.PV[4 * j + 1] * pw - v.PV[4 * j + 3] * mul2) * g_m2d[1];
+      }
+    }
+
+    // ---- Sigma -> scale, rotation (A.7 v) ----
+    if (!cov3D_precomp) {
+      const float* s3 = scales + 3 * (size_t)idx;
+      const float* q4 = rotations + 4 * (size_t)idx;
+      const float sp[3] = {scale_modifier * s3[0], scale_modifier * s3[1], scale_modifier * s3[2]};
+      // G = full symmetric gradient matrix; dL/dL = 2 G L, L = R diag(sp)
+      const float G[9] = {g_cov6[0],       0.5f * g_cov6[1], 0.5f * g_cov6[2], 0.5f * g_cov6[1], g_cov6[3],
+                          0.5f * g_cov6[4], 0.5f * g_cov6[2], 0.5f * g_cov6[4], g_cov6[5]};
+      float gR[9];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        float gs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          // dL/dL_ij = 2 * sum_k G_ik L_kj,  L_kj = R_kj sp_j
+          const float dLij = 2.f * sp[j] * (G[3 * i + 0] * R[0 + j] + G[3 * i + 1] * R[3 + j] + G[3 * i + 2] * R[6 + j]);
+          gs += dLij * R[3 * i + j];
+          gR[3 * i + j] = dLij * sp[j];
+        }
+        g_scale[j] = scale_modifier * gs;
+      }
+      const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
+      g_rot[0] = 2.f * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
+      g_rot[1] = 2.f * (y * gR[1] + z * gR[2] + y * gR[3] - 2.f * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] -
+                        2.f * x * gR[8]);
+      g_rot[2] = 2.f * (-2.f * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] -
+                        2.f * y * gR[8]);
+      g_rot[3] = 2.f * (-2.f * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2.f * z * gR[4] + y * gR[5] + x * gR[6] +
+                        y * gR[7]);
+    }
+  }
+
+  // ---- write every output (zeros for culled Gaussians: no memset pass needed) ----
+#pragma unroll
+  for (int j = 0; j < 3; j++) dL_dmeans3D[3 * (size_t)idx + j] = g_mean[j];
+  dL_dmeans2D[3 * (size_t)idx + 0] = g_m2d[0];
+  dL_dmeans2D[3 * (size_t)idx + 1] = g_m2d[1];
+  dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
+  dL_dopacities[idx] = g_opac;
+  if (dL_dcolors) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) dL_dcolors[3 * (size_t)idx + j] = g_col[j];
+  }
+  if (dL_dcov3D) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) dL_dcov3D[6 * (size_t)idx + j] = g_cov6[j];
+  }
+  if (dL_dscales) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) dL_dscales[3 * (size_t)idx + j] = g_scale[j];
+  }
+  if (dL_drotations) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) dL_drotations[4 * (size_t)idx + j] = g_rot[j];
+  }
+  if (dL_dshs || dL_ddc) {
+    // stored coefficients beyond the active degree get zero gradient
+    const int stored = sh_stride + (dL_ddc ? 1 : 0);
+    for (int k = 0; k < stored; k++) {
+      const float bk = (have_sh && k < K) ? bs[k] : 0.f;
+      float* dst = dL_ddc ? ((k == 0) ? dL_ddc + 3 * (size_t)idx : dL_dshs + ((size_t)idx * sh_stride + (k - 1)) * 3)
+                          : dL_dshs + ((size_t)idx * sh_stride + k) * 3;
+      dst[0] = bk * g_col[0];
+      dst[1] = bk * g_col[1];
+      dst[2] = bk * g_col[2];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
+                                                      const float* __restrict__ viewmatrix, uint8_t* __restrict__ present) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const float z = viewmatrix[2] * means3D[3 * (size_t)idx] + viewmatrix[6] * means3D[3 * (size_t)idx + 1] +
+                  viewmatrix[10] * means3D[3 * (size_t)idx + 2] + viewmatrix[14];
+  present[idx] = z > 0.2f ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------
+void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, int32_t* radii, char* geom,
+                               const GsrGeomLayout& L, hipStream_t st) {
+  const int P = g->P;
+  GSR_LAUNCH("preprocess_fwd", k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, st, P, s->sh_degree,
+             g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations,
+             g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width,
+             s->image_height, s->tanfovx, s->tanfovy, s->prefiltered, s->antialiasing, radii,
+             (float4*)(geom + L.rec), (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order),
+             (uint32_t*)(geom + L.tiles_touched), (ushort4*)(geom + L.rect), (uint8_t*)(geom + L.clamped),
+             (uint32_t*)(geom + L.meta));
+}
+
+void gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii,
+                               const char* geom, const GsrGeomLayout& L, const uint32_t* pos_of_slot,
+                               const float4* igrad, const gsr_grads* gr, hipStream_t st) {
+  const int P = g->P;
+  GSR_LAUNCH("preprocess_bwd", k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, st, P, s->sh_degree,
+             g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations,
+             g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width,
+             s->image_height, s->tanfovx, s->tanfovy, s->antialiasing, radii, (const uint8_t*)(geom + L.clamped),
+             (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), pos_of_slot, igrad,
+             gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities,
+             gr->dL_dscales, gr->dL_drotations, gr->dL_dcov3D);
+}
+
+void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                             hipStream_t st) {
+  GSR_LAUNCH("mark_visible", k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, st, P, means3D, viewmatrix,
+             present);
+}

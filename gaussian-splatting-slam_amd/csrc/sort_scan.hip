@@ -1,0 +1,200 @@
+// sort_scan.hip - device-wide prefix sum and stable LSD radix sort for the binning stage (gfx950, wave64).
+//
+// Replaces the two library calls of the published rasterizer's binning stage (SURVEY.md 2.3 K2
+// cub::DeviceScan::InclusiveSum and K4 cub::DeviceRadixSort::SortPairs) with hand-written kernels.
+// Both are HBM-bound integer work; the design rules are coalesced 4-B/lane streams, LDS histograms,
+// wave64 ballots for stable ranking, and no inter-workgroup hand-offs (each pass is reduce -> scan ->
+// scatter with kernel boundaries as the only grid-wide synchronisation).
+#include "gsr_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// wave / block primitives
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int lane = gsr_lane();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive block scan of one value per thread (256 threads); returns exclusive prefix, *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* total, uint32_t* lds4) {
+  const int lane = gsr_lane(), w = threadIdx.x >> 6;
+  uint32_t inc = wave_incl_scan_u32(v);
+  if (lane == 63) lds4[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t s = lds4[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scan: reduce per chunk -> (recursive) scan of chunk sums -> apply
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ src,
+                                                     const uint32_t* __restrict__ idx, uint32_t* __restrict__ sums,
+                                                     size_t n) {
+  __shared__ uint32_t lds4[4];
+  const size_t base = (size_t)blockIdx.x * GSR_SCAN_CHUNK + (size_t)threadIdx.x * GSR_SCAN_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < GSR_SCAN_ITEMS; i++) {
+    size_t k = base + i;
+    if (k < n) s += idx ? src[idx[k]] : src[k];
+  }
+  uint32_t tot;
+  block_excl_scan_u32(s, &tot, lds4);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ src,
+                                                    const uint32_t* __restrict__ idx,
+                                                    const uint32_t* __restrict__ sums_excl, uint32_t* __restrict__ out,
+                                                    size_t n, int inclusive) {
+  __shared__ uint32_t lds4[4];
+  const size_t base = (size_t)blockIdx.x * GSR_SCAN_CHUNK + (size_t)threadIdx.x * GSR_SCAN_ITEMS;
+  uint32_t v[GSR_SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < GSR_SCAN_ITEMS; i++) {
+    size_t k = base + i;
+    v[i] = (k < n) ? (idx ? src[idx[k]] : src[k]) : 0u;
+    s += v[i];
+  }
+  uint32_t tot;
+  uint32_t run = block_excl_scan_u32(s, &tot, lds4) + (sums_excl ? sums_excl[blockIdx.x] : 0u);
+#pragma unroll
+  for (int i = 0; i < GSR_SCAN_ITEMS; i++) {
+    size_t k = base + i;
+    uint32_t e = run;
+    run += v[i];
+    if (k < n) out[k] = inclusive ? run : e;
+  }
+}
+
+void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_t n, int inclusive,
+                  uint32_t* tmp, hipStream_t st) {
+  if (n == 0) return;
+  const size_t nblk = (n + GSR_SCAN_CHUNK - 1) / GSR_SCAN_CHUNK;
+  if (nblk == 1) {
+    GSR_LAUNCH("scan_apply", k_scan_apply, dim3(1), dim3(256), 0, st, src, idx, (const uint32_t*)nullptr, out, n,
+               inclusive);
+    return;
+  }
+  uint32_t* sums = tmp;
+  uint32_t* next_tmp = tmp + gsr_align(nblk * 4) / 4;
+  GSR_LAUNCH("scan_reduce", k_scan_reduce, dim3((unsigned)nblk), dim3(256), 0, st, src, idx, sums, n);
+  gsr_scan_u32(sums, nullptr, sums, nblk, 0, next_tmp, st);  // in-place exclusive scan of chunk sums
+  GSR_LAUNCH("scan_apply", k_scan_apply, dim3((unsigned)nblk), dim3(256), 0, st, src, idx, (const uint32_t*)sums,
+             out, n, inclusive);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// radix sort, 8-bit digits, stable.
+//   pass = k_radix_hist (per-chunk digit counts, table[digit][chunk]) -> exclusive scan of the table ->
+//          k_radix_scatter (re-read the chunk, stable rank by wave ballots, scatter).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t* __restrict__ table,
+                                                    size_t n, int shift, uint32_t mask, uint32_t nblk) {
+  __shared__ uint32_t hist[GSR_RADIX_SIZE];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * GSR_RADIX_CHUNK;
+#pragma unroll 4
+  for (int s = 0; s < GSR_RADIX_SUBTILES; s++) {
+    size_t k = base + (size_t)s * 256 + threadIdx.x;
+    if (k < n) atomicAdd(&hist[(keys[k] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  table[(size_t)threadIdx.x * nblk + blockIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
+                                                       const uint32_t* __restrict__ vals_in,
+                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                       const uint32_t* __restrict__ table_excl, size_t n, int shift,
+                                                       uint32_t mask, uint32_t nblk) {
+  __shared__ uint32_t digit_base[GSR_RADIX_SIZE];
+  __shared__ uint32_t wave_cnt[4][GSR_RADIX_SIZE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  digit_base[tid] = table_excl[(size_t)tid * nblk + blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < 4; i++) wave_cnt[i][tid] = 0;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * GSR_RADIX_CHUNK;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int s = 0; s < GSR_RADIX_SUBTILES; s++) {
+    const size_t k = base + (size_t)s * 256 + tid;
+    if (base + (size_t)s * 256 >= n) break;  // block-uniform
+    const bool active = k < n;
+    uint32_t key = 0, val = 0, d = 0;
+    if (active) {
+      key = keys_in[k];
+      val = vals_in ? vals_in[k] : (uint32_t)k;
+      d = (key >> shift) & mask;
+    }
+    // lanes of this wave holding the same digit
+    unsigned long long peers = __ballot(active);
+#pragma unroll
+    for (int b = 0; b < GSR_RADIX_BITS; b++) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(active && bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(peers & lt_mask);
+    if (active && rank == 0) wave_cnt[w][d] = __popcll(peers);
+    __syncthreads();
+    if (active) {
+      uint32_t off = digit_base[d] + rank;
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+        if (i < w) off += wave_cnt[i][d];
+      keys_out[off] = key;
+      vals_out[off] = val;
+    }
+    __syncthreads();
+    {
+      uint32_t add = wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+      digit_base[tid] += add;
+#pragma unroll
+      for (int i = 0; i < 4; i++) wave_cnt[i][tid] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
+                         int bits, uint32_t* tmp, hipStream_t st) {
+  if (n == 0 || bits <= 0) return 0;
+  const uint32_t nblk = (uint32_t)gsr_radix_blocks(n);
+  const size_t tab = (size_t)GSR_RADIX_SIZE * nblk;
+  uint32_t* table = tmp;
+  uint32_t* scan_tmp = tmp + gsr_align((GSR_RADIX_SIZE * ((size_t)nblk + 1)) * 4) / 4;
+  int cur = 0;
+  for (int shift = 0; shift < bits; shift += GSR_RADIX_BITS) {
+    const int nb = (bits - shift) < GSR_RADIX_BITS ? (bits - shift) : GSR_RADIX_BITS;
+    const uint32_t mask = (1u << nb) - 1u;
+    uint32_t* ki = cur ? k1 : k0;
+    uint32_t* vi = cur ? v1 : v0;
+    uint32_t* ko = cur ? k0 : k1;
+    uint32_t* vo = cur ? v0 : v1;
+    const uint32_t* vin = (shift == 0 && vals_iota) ? nullptr : vi;
+    GSR_LAUNCH("radix_hist", k_radix_hist, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, table, n, shift, mask,
+               nblk);
+    gsr_scan_u32(table, nullptr, table, tab, 0, scan_tmp, st);
+    GSR_LAUNCH("radix_scatter", k_radix_scatter, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin, ko, vo,
+               (const uint32_t*)table, n, shift, mask, nblk);
+    cur ^= 1;
+  }
+  return cur;
+}

@@ -1,0 +1,123 @@
+"""ctypes binding of libgsr_hip.so (C ABI in include/gsr.h).
+
+This is the stub a maintainer of the reference would add in place of the pybind11 `_C` extension of the
+absent `diff_gaussian_rasterization` submodule (reference gaussian_renderer/__init__.py:14).  There is no
+CPU fallback: if the HIP library is missing every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: the library shares torch's HIP runtime - same SONAME)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class gsr_settings(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("bg", C.c_void_p), ("scale_modifier", C.c_float),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("sh_degree", C.c_int32), ("campos", C.c_void_p),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32), ("antialiasing", C.c_int32),
+    ]
+
+
+class gsr_gaussians(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("sh_coeffs", C.c_int32),
+        ("means3D", C.c_void_p), ("dc", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+    ]
+
+
+class gsr_grads(C.Structure):
+    _fields_ = [
+        ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_ddc", C.c_void_p), ("dL_dshs", C.c_void_p),
+        ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+        ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+    ]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "gsr_abi_version": (C.c_int, []),
+    "gsr_last_error": (C.c_char_p, []),
+    "gsr_geometry_state_bytes": (C.c_size_t, [C.c_int32]),
+    "gsr_image_state_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gsr_binning_state_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    "gsr_backward_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "gsr_forward_prepare": (C.c_int64, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_void_p]),
+    "gsr_forward_render": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_void_p]),
+    "gsr_backward": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                               C.POINTER(gsr_grads), C.c_void_p]),
+    "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_debug_geometry_views": (C.c_int, [C.c_void_p, C.c_int32] + [C.POINTER(C.c_void_p)] * 6),
+    "gsr_debug_binning_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p)]),
+    "gsr_debug_image_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p)]),
+    "gsr_profile_enable": (None, [C.c_int32]),
+    "gsr_profile_reset": (None, []),
+    "gsr_profile_read": (C.c_int32, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
+}
+
+_lib = None
+
+
+class GsrError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libgsr_hip.so once.  Raises (never falls back) when the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GsrError(
+                f"{LIB_PATH} not found: the HIP rasterizer is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C gaussian-splatting-slam_amd/csrc`). "
+                "There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            f = getattr(l, name)         # AttributeError if a declared symbol is not exported
+            f.restype = res
+            f.argtypes = args
+        if l.gsr_abi_version() != 1:
+            raise GsrError(f"libgsr_hip.so ABI {l.gsr_abi_version()} != 1")
+        _lib = l
+    return _lib
+
+
+def last_error() -> str:
+    return lib().gsr_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    if rc < 0:
+        raise GsrError(f"libgsr_hip error {rc}: {last_error()}")
+    return rc
+
+
+def ptr(t):
+    """device pointer of a tensor, or None"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def profile_read():
+    l = lib()
+    n = l.gsr_profile_read(None, None, None, 0)
+    names = (C.c_char_p * n)()
+    ms = (C.c_double * n)()
+    calls = (C.c_int64 * n)()
+    n = l.gsr_profile_read(names, ms, calls, n)
+    return {names[i].decode(): (ms[i], calls[i]) for i in range(n)}

@@ -1,0 +1,6 @@
+"""Host-side helpers around the rasterizer path: camera conventions and synthetic scenes."""
+from .cameras import MiniCam, camera_from_RT, look_at_camera, fibonacci_cameras, fov2focal, focal2fov, \
+    world_to_view, projection_matrix
+from .synthetic import RawGaussians, make_gaussians, make_config, CONFIGS
+from .model import GaussianModel
+from .sh import eval_sh, RGB2SH, SH2RGB

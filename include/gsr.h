@@ -1,0 +1,145 @@
+/*
+ * gsr.h - C ABI of the MI355X-native differentiable Gaussian rasterizer (libgsr_hip.so).
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json:north_star.  It replaces the
+ * native half of the third-party module the reference imports at
+ *     /root/reference/gaussian_renderer/__init__.py:14
+ *         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+ * i.e. what `_C.rasterize_gaussians`, `_C.rasterize_gaussians_backward` and `_C.mark_visible` of
+ * graphdeco-inria/diff-gaussian-rasterization@9c5c2028 (pin: reference results.md:2, .gitmodules:4-6) do for
+ * the call at gaussian_renderer/__init__.py:90-109.  The source of that module is NOT in the reference tree
+ * (SURVEY.md 0.1), so entry points cite the reference call site / contract they serve.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked "host";
+ *   - all tensors are contiguous; fp32 unless stated; matrices are the reference's row-major 4x4 tensors
+ *     (world_view_transform = W2C^T, full_proj_transform = (P.W2C)^T; reference scene/cameras.py:69-71);
+ *   - `stream` is a hipStream_t passed as void*; every call enqueues on it and is re-entrant per stream;
+ *   - the library never allocates device memory on the hot path: the caller owns three opaque state
+ *     buffers (geometry / binning / image) that carry forward -> backward, sized by the gsr_*_bytes()
+ *     queries (the reference's rasterizer keeps the same three buffers as torch uint8 tensors in its
+ *     autograd ctx - SURVEY.md 8b "Ownership");
+ *   - return value < 0 is an error code; gsr_last_error() gives the message (thread-local).
+ */
+#ifndef GSR_H_
+#define GSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+enum {
+  GSR_OK = 0,
+  GSR_ERR_INVALID_ARGUMENT = -1, /* bad combination of inputs (both/neither of shs|colors_precomp ...) */
+  GSR_ERR_HIP = -2,              /* a HIP runtime call failed */
+  GSR_ERR_PREFILTERED_CULLED = -3, /* prefiltered=1 but a point failed the near-plane test */
+  GSR_ERR_TOO_MANY_INSTANCES = -4, /* num_rendered does not fit 31 bits */
+  GSR_ERR_STATE_TOO_SMALL = -5   /* a caller-provided state buffer is smaller than required */
+};
+
+/* GaussianRasterizationSettings, reference gaussian_renderer/__init__.py:36-50 (13 fields). */
+typedef struct gsr_settings {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  const float* bg;          /* [3]  */
+  float scale_modifier;
+  const float* viewmatrix;  /* [16] */
+  const float* projmatrix;  /* [16] */
+  int32_t sh_degree;        /* active degree, 0..3 */
+  const float* campos;      /* [3]  */
+  int32_t prefiltered;
+  int32_t debug;            /* 1: synchronise and check after every kernel */
+  int32_t antialiasing;
+} gsr_settings;
+
+/* Arguments of GaussianRasterizer.forward, reference gaussian_renderer/__init__.py:90-109.
+ * Exactly one of {shs (+ optional dc), colors_precomp} and exactly one of {scales+rotations, cov3D_precomp}
+ * must be non-NULL (same rule, same error, as the reference's rasterizer). */
+typedef struct gsr_gaussians {
+  int32_t P;                   /* number of Gaussians */
+  int32_t sh_coeffs;           /* coefficients per channel stored in `shs` (row stride), e.g. 16 (or 15 with dc) */
+  const float* means3D;        /* [P,3] */
+  const float* dc;             /* [P,1,3] or NULL: SH band 0 kept separately (the `separate_sh` call form, :90-99) */
+  const float* shs;            /* [P,sh_coeffs,3] or NULL */
+  const float* colors_precomp; /* [P,3] or NULL */
+  const float* opacities;      /* [P] */
+  const float* scales;         /* [P,3] or NULL */
+  const float* rotations;      /* [P,4] (w,x,y,z), used as given, or NULL */
+  const float* cov3D_precomp;  /* [P,6] (xx,xy,xz,yy,yz,zz) or NULL */
+} gsr_gaussians;
+
+/* Gradients returned by the backward, in the order the reference's autograd Function returns them
+ * (SURVEY.md 8(a) a3).  Every non-NULL pointer is fully written (zeros for culled Gaussians). */
+typedef struct gsr_grads {
+  float* dL_dmeans3D;   /* [P,3] */
+  float* dL_dmeans2D;   /* [P,3] screen-space gradient in NDC units, z = 0 (consumed by
+                           scene/gaussian_model.py:431-433 add_densification_stats) */
+  float* dL_ddc;        /* [P,1,3] or NULL */
+  float* dL_dshs;       /* [P,sh_coeffs,3] or NULL */
+  float* dL_dcolors;    /* [P,3] or NULL (colors_precomp) */
+  float* dL_dopacities; /* [P] */
+  float* dL_dscales;    /* [P,3] or NULL */
+  float* dL_drotations; /* [P,4] or NULL */
+  float* dL_dcov3D;     /* [P,6] or NULL (cov3D_precomp) */
+} gsr_grads;
+
+int gsr_abi_version(void);
+const char* gsr_last_error(void);
+
+/* State-buffer sizes (bytes).  Binning state depends on num_rendered, known after gsr_forward_prepare. */
+size_t gsr_geometry_state_bytes(int32_t P);
+size_t gsr_image_state_bytes(int32_t image_width, int32_t image_height);
+size_t gsr_binning_state_bytes(int32_t P, int32_t image_width, int32_t image_height, int64_t num_rendered);
+size_t gsr_backward_scratch_bytes(int32_t P, int64_t num_rendered);
+
+/* Forward, phase 1: preprocess (projection, EWA covariance, SH->RGB), depth ordering and the tile-count
+ * prefix sum.  Writes radii[P] (int32; 0 = culled; reference :118-121 `radii`, `visibility_filter`).
+ * Synchronises `stream` once to read num_rendered back (the reference rasterizer has the same single
+ * host sync).  Returns num_rendered >= 0 or an error code. */
+int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
+                            size_t geometry_bytes, int32_t* radii, void* stream);
+
+/* Forward, phase 2: instance emission, tile sort, tile ranges and 16x16-tile alpha compositing.
+ * Writes out_color[3,H,W] and out_invdepth[1,H,W] (reference :90,:101 `rendered_image`, `depth_image`).
+ * `for_backward` != 0 additionally records what gsr_backward needs in the state buffers. */
+int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
+                       void* binning_state, size_t binning_bytes, int64_t num_rendered, void* image_state,
+                       size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
+                       void* stream);
+
+/* Backward of the call above.  dL_dinvdepth may be NULL (treated as zero). */
+int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii,
+                 const void* geometry_state, const void* binning_state, const void* image_state,
+                 int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth,
+                 void* scratch, size_t scratch_bytes, const gsr_grads* grads, void* stream);
+
+/* GaussianRasterizer.markVisible (near-plane test).  present[P] uint8. */
+int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream);
+
+/* Introspection for tests / bench: DEVICE pointers into the opaque state buffers (valid while the buffer lives). */
+int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float** rec48, const uint32_t** depth_keys_sorted,
+                             const uint32_t** order, const uint32_t** tiles_touched, const uint16_t** rect,
+                             const uint32_t** offsets);
+int gsr_debug_binning_views(const void* binning_state, int32_t image_width, int32_t image_height,
+                            int64_t num_rendered, const uint32_t** point_list, const uint32_t** ranges);
+int gsr_debug_image_views(const void* image_state, int32_t image_width, int32_t image_height,
+                          const float** final_T, const uint32_t** n_contrib);
+
+/* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline block). */
+void gsr_profile_enable(int32_t on);
+void gsr_profile_reset(void);
+/* Fills up to `max` entries; returns the number of distinct kernels.  `names` receives pointers to
+ * static strings. */
+int32_t gsr_profile_read(const char** names, double* total_ms, int64_t* calls, int32_t max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_ */
