@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""bench.py - BASELINE.json metric on the MI355X-native rasterizer path.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+Workload (N=1 and N>1): BASELINE.json configs[2] - the configuration the metric is quoted on
+("@1080p, 1M Gaussians"): 1,000,000 synthetic Gaussians, SH degree 3, 1920x1080, 100 synthetic views
+(SURVEY.md Appendix C recipe, seeds 3000/3001).  A "step" is one training iteration per rank with the shape of
+reference train.py:96-137,170-179: render() forward -> (1-l)L1 + l(1-SSIM) loss -> backward -> Adam step; with N
+ranks every rank renders a different view and the 59 floats/Gaussian of gradients are all-reduced (RCCL) before
+Adam.  `value` = view-iterations per second over the whole job (N*K / max-over-ranks time): weak scaling.
+
+Extra keys on the same JSON line: `roofline` (dominant kernel, algorithmic bytes / measured HIP-event time),
+`cpu_baseline` (the CPU oracle timed on a bounded sample on rank 0 at N=1), `fwd_mpix_per_s`, `kernels`.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-slam_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+_T0 = time.time()
+
+
+def log(msg):
+    """progress to stderr (stdout carries exactly one JSON line)"""
+    print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """CPU threads this process may really use (the GPU box gives a 16-CPU share of a bigger host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
+
+
+def build_scene(args, device, rank, world):
+    from scene_utils import make_config, GaussianModel, make_gaussians
+    from gaussian_renderer import render, PipelineParams
+    raw, cams, cfg = make_config(args.config, device="cpu", P=args.gaussians, views=args.views,
+                                 W=args.width, H=args.height)
+    for c in cams:
+        c.to(device)
+    pipe = PipelineParams(antialiasing=bool(cfg.get("antialiasing", False)))
+    bg = torch.zeros(3, device=device)
+    # hidden "teacher": same recipe, different seed for colour/opacity perturbation -> ground-truth images
+    teacher_raw = make_gaussians(cfg["P"], cfg["deg"], 1000 * args.config)
+    gen = torch.Generator().manual_seed(1000 * args.config + 7)
+    teacher_raw.features_dc += 0.3 * torch.randn(teacher_raw.features_dc.shape, generator=gen)
+    teacher_raw.xyz += 0.002 * torch.randn(teacher_raw.xyz.shape, generator=gen)
+    teacher = GaussianModel.from_raw(teacher_raw.to(device), requires_grad=False)
+    my_views = list(range(len(cams)))[rank::world]
+    log(f"scene generated: P={cfg['P']} views={len(cams)}; rendering {len(my_views)} teacher views")
+    gts = {}
+    with torch.no_grad():
+        for v in my_views:
+            gts[v] = render(cams[v], teacher, pipe, bg)["render"].clamp(0, 1).clone()
+    del teacher
+    torch.cuda.synchronize()
+    log("teacher views rendered")
+    model = GaussianModel.from_raw(raw.to(device), requires_grad=True)
+    return model, cams, gts, my_views, pipe, bg, cfg, render
+
+
+def kernel_table(prof, R, N, P, M):
+    """Algorithmic HBM bytes per launch (SURVEY.md 8(d) per-unit figures x units per launch; DESIGN.md 'Kernels')."""
+    b_in = 44 + 12 * M
+    alg = {
+        "preprocess_fwd": P * (b_in + 75),
+        "render_fwd": 44 * R + 24 * N,
+        "render_bwd": 84 * R + 24 * N,
+        "preprocess_bwd": P * (2 * b_in + 79) + 44 * R,
+        "emit_instances": 20 * P + 8 * R,
+        "finalize_bins": 16 * R,
+    }
+    out = {}
+    for name, (ms, calls) in prof.items():
+        if calls == 0:
+            continue
+        avg = ms / calls
+        e = {"avg_ms": round(avg, 4), "calls": int(calls)}
+        if name in alg:
+            e["alg_bytes"] = int(alg[name])
+            e["gbps"] = round(alg[name] / (avg * 1e-3) / 1e9, 1)
+        out[name] = e
+    return out
+
+
+def cpu_baseline(args, model, cam, gt, bg, cfg, gpu_image):
+    """CPU oracle (pure-PyTorch restatement, `kind: port`) on a bounded sample of the SAME view:
+    full preprocess + binning, forward+backward compositing of n1 and n2 tiles; per-tile slope extrapolated to
+    all tiles.  Also returns PSNR(GPU image, oracle) on the sampled tiles."""
+    from oracle import gs_oracle as O
+
+    def oracle_settings(cam, deg, bg_, antialiasing):
+        return O.OracleSettings(int(cam.image_height), int(cam.image_width), math.tan(cam.FoVx * 0.5),
+                                math.tan(cam.FoVy * 0.5), bg_, 1.0, cam.world_view_transform.cpu(),
+                                cam.full_proj_transform.cpu(), deg, cam.camera_center.cpu(), False, False, antialiasing)
+    torch.set_num_threads(host_threads())
+    W, H = cfg["W"], cfg["H"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ntiles = gx * gy
+    gen = torch.Generator().manual_seed(5)
+    perm = torch.randperm(ntiles, generator=gen).tolist()
+    n1, n2 = (args.cpu_tiles, 3 * args.cpu_tiles)
+    n2 = min(n2, ntiles)
+    n1 = min(n1, n2)
+    times = []
+    psnr_db = None
+    for n in (n1, n2):
+        tiles = sorted(perm[:n])
+        leaves = [p.detach().cpu().clone().requires_grad_(True) for p in model.parameters()]
+        xyz, fdc, frest, opac, scal, rot = leaves
+        t0 = time.perf_counter()
+        s = oracle_settings(cam, cfg["deg"], bg.cpu(), antialiasing=bool(cfg.get("antialiasing", False)))
+        m2d = torch.zeros(xyz.shape[0], 3, requires_grad=True)
+        color, radii, invd = O.rasterize(xyz, m2d, torch.sigmoid(opac), s, shs=torch.cat((fdc, frest), 1),
+                                         scales=torch.exp(scal), rotations=torch.nn.functional.normalize(rot),
+                                         tiles=tiles)
+        mask = torch.zeros(1, H, W)
+        for t in tiles:
+            ty, tx = divmod(t, gx)
+            mask[:, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = 1
+        loss = (torch.abs(color - gt.cpu()) * mask).sum() / (3 * H * W)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        log(f"cpu oracle: {n} tiles fwd+bwd in {times[-1]:.1f}s")
+        if n == n2:
+            sel = mask.bool().expand(3, H, W)
+            mse = ((color.detach() - gpu_image.cpu())[sel] ** 2).mean().item()
+            psnr_db = 99.0 if mse == 0 else 10 * math.log10(1.0 / mse)
+    per_tile = (times[1] - times[0]) / max(1, (n2 - n1))
+    fixed = max(0.0, times[0] - per_tile * n1)
+    est = fixed + per_tile * ntiles
+    return {
+        "value": round(1.0 / est, 5), "unit": "view-iterations/s (fwd+bwd, extrapolated)",
+        "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"view 0 of the bench scene: full preprocess+binning+their backward ({fixed:.1f}s) plus "
+                  f"{n1} and {n2} of {ntiles} tiles composited fwd+bwd ({per_tile * 1e3:.1f} ms/tile slope), "
+                  f"scaled to {ntiles} tiles; CPU work measured {times[0] + times[1]:.1f}s",
+        "measured_s": round(times[0] + times[1], 2),
+        "psnr_gpu_vs_oracle_db_on_sample": None if psnr_db is None else round(psnr_db, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--views", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--cpu-tiles", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    torch.set_num_threads(host_threads())
+    from scene_utils import init_from_env, Trainer
+    rank, world, local = init_from_env("nccl")
+    log(f"rank {os.environ.get('RANK', '0')} start; host threads {host_threads()} (cpu_count {os.cpu_count()})")
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    model, cams, gts, my_views, pipe, bg, cfg, render = build_scene(args, device, rank, world)
+    trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank)
+    P = cfg["P"]
+    M = (cfg["deg"] + 1) ** 2
+    W, H = cfg["W"], cfg["H"]
+
+    def view_at(i):
+        return my_views[i % len(my_views)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(view_at(i))
+    barrier()
+    log("warmup done")
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(view_at(args.warmup + i))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+    result = {
+        "metric": "train_iters_per_sec", "value": round(world * args.steps / elapsed, 3),
+        "unit": "view-iterations/s (render fwd + L1/DSSIM loss + bwd + Adam)", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{args.config - 1}]: {P} Gaussians, SH degree {cfg['deg']}, "
+                               f"{W}x{H}, {len(cams)} views, one view per rank per step, all-reduce of "
+                               f"{59 if cfg['deg'] == 3 else 11 + 3 * M}-float/Gaussian grads when N>1",
+                   "gaussians": P, "sh_degree": cfg["deg"], "width": W, "height": H, "views": len(cams),
+                   "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}"},
+    }
+
+    # ---- untimed extras (rank 0 reports) ----
+    from diff_gaussian_rasterization import _C
+    lib = _C.lib()
+    # forward-only throughput (reference render.py:37-49 path: no_grad)
+    with torch.no_grad():
+        for _ in range(3):
+            render(cams[view_at(0)], model, pipe, bg)
+        torch.cuda.synchronize()
+        nf = max(5, min(30, args.steps))
+        t0 = time.perf_counter()
+        for i in range(nf):
+            render(cams[view_at(i)], model, pipe, bg)
+        torch.cuda.synchronize()
+        fwd_s = (time.perf_counter() - t0) / nf
+    result["fwd_mpix_per_s"] = round(W * H / fwd_s / 1e6, 1)
+    result["fwd_ms"] = round(fwd_s * 1e3, 3)
+
+    if not args.no_kernel_profile:
+        lib.gsr_profile_enable(1)
+        lib.gsr_profile_reset()
+        import diff_gaussian_rasterization as dgr
+        nprof = max(3, min(10, args.steps))
+        Rs = []
+        for i in range(nprof):
+            trainer.step(view_at(i))
+            Rs.append(dgr.last_call_stats["num_rendered"])   # measured R of each profiled view
+        torch.cuda.synchronize()
+        prof = _C.profile_read()
+        lib.gsr_profile_enable(0)
+        R = sum(Rs) / len(Rs)
+        kt = kernel_table(prof, R, W * H, P, M)
+        result["num_rendered_avg"] = int(R)
+        result["kernels"] = kt
+        named = {k: v for k, v in kt.items() if "alg_bytes" in v}
+        if named:
+            dom = max(named, key=lambda k: named[k]["avg_ms"])
+            d = named[dom]
+            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": d["gbps"], "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBS, 5), "traffic": None,
+                                  "avg_ms": d["avg_ms"], "alg_bytes": d["alg_bytes"],
+                                  "note": "render kernels are FP32-VALU/LDS bound, not HBM bound (DESIGN.md)"}
+
+    log("extras done; cpu baseline next")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        v0 = view_at(0)
+        with torch.no_grad():
+            gpu_img = render(cams[v0], model, pipe, bg)["render"]
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, model, cams[v0], gts[v0], bg, cfg, gpu_img)
+        except Exception as e:  # the baseline is a reported extra; never lose the headline number to it
+            result["cpu_baseline"] = {"value": None, "error": repr(e)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

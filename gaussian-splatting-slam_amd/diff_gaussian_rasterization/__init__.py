@@ -36,6 +36,10 @@ class GaussianRasterizationSettings(NamedTuple):
     antialiasing: bool = False
 
 
+# statistics of the most recent forward call (bench.py reports the measured num_rendered with every number)
+last_call_stats = {"num_rendered": 0}
+
+
 def _f32c(t):
     if t is None or t.numel() == 0:
         return None
@@ -102,6 +106,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning), binning.numel(), R,
                                             _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invdepth),
                                             1 if needs_grad else 0, _stream()))
+        last_call_stats["num_rendered"] = int(R)
         ctx.raster_settings = rs
         ctx.num_rendered = R
         ctx.has = (dc is not None, sh is not None, colors_precomp is not None, scales is not None,

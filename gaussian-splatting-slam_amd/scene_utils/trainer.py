@@ -1,0 +1,52 @@
+"""Training-step harness with the shape of the reference loop (train.py:96-137 forward+loss+backward,
+:159-160 densification statistics, :170-179 optimizer step), used by bench.py and the tests.  It is a CALLER of the
+hot path (render()); the renderer is injected so CPU tests can drive the same logic with the oracle."""
+from __future__ import annotations
+
+import torch
+
+from .losses import training_loss
+from .parallel import GradBucket
+
+
+class Trainer:
+    def __init__(self, model, cameras, gt_images, render_fn, pipe, bg, lambda_dssim=0.2, world=1, rank=0,
+                 fused_adam=None, depth_targets=None, depth_weight=0.0):
+        self.model, self.cameras, self.gt_images = model, cameras, gt_images
+        self.render_fn, self.pipe, self.bg = render_fn, pipe, bg
+        self.lambda_dssim = lambda_dssim
+        self.world, self.rank = world, rank
+        dev = model.get_xyz.device
+        if fused_adam is None:
+            fused_adam = dev.type == "cuda"
+        kw = dict(lr=0.0, eps=1e-15)                          # reference scene/gaussian_model.py:170
+        if fused_adam:
+            kw["fused"] = True
+        self.optimizer = torch.optim.Adam(model.param_groups(), **kw)
+        self.bucket = GradBucket(model.parameters()) if world > 1 else None
+        P = model.get_xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros(P, 1, device=dev)
+        self.denom = torch.zeros(P, 1, device=dev)
+        self.max_radii2D = torch.zeros(P, device=dev)
+        self.depth_targets, self.depth_weight = depth_targets, depth_weight
+        self.last = {}
+
+    def step(self, view_idx: int):
+        cam = self.cameras[view_idx]
+        pkg = self.render_fn(cam, self.model, self.pipe, self.bg)
+        image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
+        loss = training_loss(image, self.gt_images[view_idx], self.lambda_dssim)
+        if self.depth_weight > 0 and self.depth_targets is not None:
+            loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[view_idx]).mean()
+        loss.backward()
+        with torch.no_grad():
+            # densification statistics are per-view: norm BEFORE any cross-rank reduction
+            self.max_radii2D[vis] = torch.max(self.max_radii2D[vis], radii[vis].float())
+            self.xyz_gradient_accum[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)
+            self.denom[vis] += 1
+            if self.bucket is not None:
+                self.bucket.all_reduce_mean(self.world)
+            self.optimizer.step()
+            self.optimizer.zero_grad(set_to_none=True)
+        self.last = dict(loss=loss.detach(), image=image.detach(), radii=radii)
+        return self.last

@@ -8,7 +8,7 @@ outputs on seeded inputs.  Only DATA (inputs + expected outputs) is written; no 
 Pins:  SH->RGB (utils/sh_utils.py:57-112), getWorld2View2 / getProjectionMatrix / fov2focal / focal2fov
 (utils/graphics_utils.py:38-77), MiniCam.camera_center (scene/cameras.py:74-85, loaded by file path because
 scene/__init__.py cannot be imported - SURVEY §0.3), psnr (utils/image_utils.py:17-19),
-l1_loss (utils/loss_utils.py:40-52), RGB2SH (utils/sh_utils.py:114-115).
+l1_loss / ssim (utils/loss_utils.py:40-52,100-159), RGB2SH (utils/sh_utils.py:114-115).
 """
 import importlib.util
 import math
@@ -27,7 +27,7 @@ def main():
     from utils.sh_utils import eval_sh, RGB2SH                       # noqa: E402
     from utils.graphics_utils import getWorld2View2, getProjectionMatrix, fov2focal, focal2fov  # noqa: E402
     from utils.image_utils import psnr                               # noqa: E402
-    from utils.loss_utils import l1_loss                             # noqa: E402
+    from utils.loss_utils import l1_loss, ssim                       # noqa: E402
     spec = importlib.util.spec_from_file_location("ref_cameras", os.path.join(REF, "scene", "cameras.py"))
     ref_cameras = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ref_cameras)
@@ -87,6 +87,10 @@ def main():
     out["img_a"] = a.numpy(); out["img_b"] = b.numpy()
     out["psnr_ab"] = psnr(a, b).numpy()
     out["l1_ab"] = np.array(l1_loss(a, b).item())
+    a2 = torch.rand(3, 40, 52, generator=gen)
+    b2 = (a2 + 0.1 * torch.randn(3, 40, 52, generator=gen)).clamp(0, 1)
+    out["img_a2"] = a2.numpy(); out["img_b2"] = b2.numpy()
+    out["ssim_ab2"] = np.array(ssim(a2, b2).item())                  # utils/loss_utils.py:100-159
 
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: v.shape for k, v in out.items()})
