@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--cpu-tiles", type=int, default=64)
+    ap.add_argument("--optimizer", default="hip", choices=["hip", "hip_sparse", "torch"])
+    ap.add_argument("--loss", default="hip", choices=["hip", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
@@ -182,7 +184,8 @@ def main():
     device = torch.device("cuda", local)
 
     model, cams, gts, my_views, pipe, bg, cfg, render = build_scene(args, device, rank, world)
-    trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank)
+    trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=args.optimizer,
+                      loss=args.loss)
     P = cfg["P"]
     M = (cfg["deg"] + 1) ** 2
     W, H = cfg["W"], cfg["H"]
@@ -220,7 +223,10 @@ def main():
                                f"{W}x{H}, {len(cams)} views, one view per rank per step, all-reduce of "
                                f"{59 if cfg['deg'] == 3 else 11 + 3 * M}-float/Gaussian grads when N>1",
                    "gaussians": P, "sh_degree": cfg["deg"], "width": W, "height": H, "views": len(cams),
-                   "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}"},
+                   "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}",
+                   "loss": "L1 + 0.2 DSSIM (" + ("HIP fused SSIM" if args.loss == "hip" else "torch conv2d SSIM") + ")",
+                   "optimizer": {"hip": "Adam, one-launch HIP kernel (torch.optim.Adam semantics)",
+                                 "hip_sparse": "SparseGaussianAdam (HIP)", "torch": "torch.optim.Adam"}[args.optimizer]},
     }
 
     # ---- untimed extras (rank 0 reports) ----

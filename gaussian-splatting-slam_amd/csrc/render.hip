@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   }
 }
 
+#define BWD_BATCH 128   // entries staged per round in the backward (4 per-wave gradient slabs must fit LDS)
+
 __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                                                     const uint32_t* __restrict__ point_list,
                                                     const float4* __restrict__ rec, const float* __restrict__ bg,
@@ -90,10 +92,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
                                                     const uint32_t* __restrict__ n_contrib,
                                                     const float* __restrict__ dL_dpix,
                                                     const float* __restrict__ dL_dinvdepth, float4* __restrict__ igrad) {
-  __shared__ float4 s0[256], s1[256], s2[256];
-  __shared__ float4 acc4[256 * GSR_IGRAD_F4];
+  __shared__ float4 s0[BWD_BATCH], s1[BWD_BATCH], s2[BWD_BATCH];
+  // one private slab per wave: no LDS atomics, and the 4 partial sums are added in a FIXED order at flush time,
+  // so gradients are bitwise reproducible
+  __shared__ float4 slab[4][BWD_BATCH * GSR_IGRAD_F4];
   __shared__ int s_max;
-  float* acc = reinterpret_cast<float*>(acc4);
 
   const int tile = blockIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -136,26 +139,29 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
     dst[0] = z4; dst[1] = z4; dst[2] = z4;
   }
 
-  const int rounds = (toDo + 255) / 256;
+  const int rounds = (toDo + BWD_BATCH - 1) / BWD_BATCH;
   float T = T_final;
   float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, ad = 0.f;        // colour / invdepth accumulated behind
   float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f, last_alpha = 0.f;
   const float halfW = 0.5f * W, halfH = 0.5f * H;
+  float4* myslab = slab[w];
 
   for (int b = 0; b < rounds; b++) {
     __syncthreads();
-    const int e_idx = toDo - 1 - (b * 256 + tid);  // back-to-front staging
-    if (e_idx >= 0) {
+    const int e_idx = toDo - 1 - (b * BWD_BATCH + tid);  // back-to-front staging (threads 0..127)
+    if (tid < BWD_BATCH && e_idx >= 0) {
       const size_t id = point_list[range.x + e_idx];
       s0[tid] = rec[3 * id + 0];
       s1[tid] = rec[3 * id + 1];
       s2[tid] = rec[3 * id + 2];
     }
-    acc4[3 * tid + 0] = z4; acc4[3 * tid + 1] = z4; acc4[3 * tid + 2] = z4;
+    // each wave clears its own slab (384 float4 / 64 lanes)
+#pragma unroll
+    for (int i = 0; i < (BWD_BATCH * GSR_IGRAD_F4) / 64; i++) myslab[i * 64 + lane] = z4;
     __syncthreads();
-    const int n = min(256, toDo - b * 256);
+    const int n = min(BWD_BATCH, toDo - b * BWD_BATCH);
     for (int j = 0; j < n; j++) {
-      const int entry1 = toDo - (b * 256 + j);  // 1-based list position of this entry
+      const int entry1 = toDo - (b * BWD_BATCH + j);  // 1-based list position of this entry
       const float4 a = s0[j];
       const float4 bb = s1[j];
       const float dx = a.x - pxf, dy = a.y - pyf;
@@ -196,18 +202,23 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       v6 = gsr_wave_sum_to_lane63(v6); v7 = gsr_wave_sum_to_lane63(v7);
       v8 = gsr_wave_sum_to_lane63(v8); v9 = gsr_wave_sum_to_lane63(v9);
       if (lane == 63) {
-        float* dst = acc + 12 * j;
-        atomicAdd(dst + 0, v0); atomicAdd(dst + 1, v1); atomicAdd(dst + 2, v2); atomicAdd(dst + 3, v3);
-        atomicAdd(dst + 4, v4); atomicAdd(dst + 5, v5); atomicAdd(dst + 6, v6); atomicAdd(dst + 7, v7);
-        atomicAdd(dst + 8, v8); atomicAdd(dst + 9, v9);
+        myslab[3 * j + 0] = make_float4(v0, v1, v2, v3);
+        myslab[3 * j + 1] = make_float4(v4, v5, v6, v7);
+        myslab[3 * j + 2] = make_float4(v8, v9, 0.f, 0.f);
       }
     }
     __syncthreads();
-    if (e_idx >= 0) {
-      float4* dst = igrad + (size_t)GSR_IGRAD_F4 * (range.x + e_idx);
-      dst[0] = acc4[3 * tid + 0];
-      dst[1] = acc4[3 * tid + 1];
-      dst[2] = acc4[3 * tid + 2];
+    // flush: 128 entries x 3 float4 = 384 float4, fixed summation order over the 4 waves
+    for (int q = tid; q < n * GSR_IGRAD_F4; q += 256) {
+      const int j = q / GSR_IGRAD_F4, part = q - j * GSR_IGRAD_F4;
+      const float4 a0 = slab[0][q], a1 = slab[1][q], a2 = slab[2][q], a3 = slab[3][q];
+      float4 r;
+      r.x = ((a0.x + a1.x) + a2.x) + a3.x;
+      r.y = ((a0.y + a1.y) + a2.y) + a3.y;
+      r.z = ((a0.z + a1.z) + a2.z) + a3.z;
+      r.w = ((a0.w + a1.w) + a2.w) + a3.w;
+      const int e = toDo - 1 - (b * BWD_BATCH + j);
+      igrad[(size_t)GSR_IGRAD_F4 * (range.x + e) + part] = r;
     }
   }
 }

@@ -66,6 +66,13 @@ EXPORTS = {
                                           C.POINTER(C.c_void_p)]),
     "gsr_debug_image_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p)]),
+    "gsr_fused_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),
+    "gsr_fused_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
+    "gsr_adam_step": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "gsr_sparse_adam_step": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                       C.c_void_p]),
     "gsr_profile_enable": (None, [C.c_int32]),
     "gsr_profile_reset": (None, []),
     "gsr_profile_read": (C.c_int32, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
@@ -121,3 +128,45 @@ def profile_read():
     calls = (C.c_int64 * n)()
     n = l.gsr_profile_read(names, ms, calls, n)
     return {names[i].decode(): (ms[i], calls[i]) for i in range(n)}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- the two functions reference utils/loss_utils.py:16-19 imports from `diff_gaussian_rasterization._C` ----
+def _ssim_forward(C1, C2, img1, img2, want_partials):
+    if not img1.is_cuda:
+        raise GsrError("fusedssim needs tensors on the HIP device (no CPU path)")
+    img1 = img1.detach().float().contiguous()
+    img2 = img2.detach().float().contiguous()
+    H, W = int(img1.shape[-2]), int(img1.shape[-1])
+    planes = img1.numel() // (H * W) if H * W else 0
+    out = torch.empty_like(img1)
+    parts = [torch.empty_like(img1) for _ in range(3)] if want_partials else [None, None, None]
+    with torch.cuda.device(img1.device):
+        check(lib().gsr_fused_ssim_forward(planes, H, W, float(C1), float(C2), ptr(img1), ptr(img2), ptr(out),
+                                           ptr(parts[0]), ptr(parts[1]), ptr(parts[2]), _stream()))
+    return out, parts, img1, img2
+
+
+def fusedssim(C1, C2, img1, img2):
+    """-> ssim_map, same shape as img1 (reference utils/loss_utils.py:27)."""
+    return _ssim_forward(C1, C2, img1, img2, False)[0]
+
+
+def fusedssim_backward(C1, C2, img1, img2, dL_dmap, partials=None):
+    """-> dL/dimg1 (reference utils/loss_utils.py:37).  `partials` (from a forward that kept them) avoids recomputation."""
+    if partials is None:
+        _, partials, img1, img2 = _ssim_forward(C1, C2, img1, img2, True)
+    else:
+        img1 = img1.detach().float().contiguous()
+        img2 = img2.detach().float().contiguous()
+    H, W = int(img1.shape[-2]), int(img1.shape[-1])
+    planes = img1.numel() // (H * W) if H * W else 0
+    g = dL_dmap.detach().float().expand_as(img1).contiguous()
+    out = torch.empty_like(img1)
+    with torch.cuda.device(img1.device):
+        check(lib().gsr_fused_ssim_backward(planes, H, W, ptr(img1), ptr(img2), ptr(g), ptr(partials[0]),
+                                            ptr(partials[1]), ptr(partials[2]), ptr(out), _stream()))
+    return out

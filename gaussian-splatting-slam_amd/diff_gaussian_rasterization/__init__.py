@@ -195,3 +195,5 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians(means3D, means2D, dc, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, self.raster_settings)
 
+
+from .sparse_adam import SparseGaussianAdam, FusedAdam  # noqa: E402,F401   (reference train.py:37-41)

@@ -4,6 +4,6 @@ from .cameras import MiniCam, camera_from_RT, look_at_camera, fibonacci_cameras,
 from .synthetic import RawGaussians, make_gaussians, make_config, CONFIGS
 from .model import GaussianModel
 from .sh import eval_sh, RGB2SH, SH2RGB
-from .losses import l1_loss, psnr, ssim, training_loss
+from .losses import l1_loss, psnr, ssim, training_loss, training_loss_fused
 from .parallel import init_from_env, shard_views, GradBucket, reduce_densification_stats
 from .trainer import Trainer

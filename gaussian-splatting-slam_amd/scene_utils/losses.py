@@ -49,6 +49,14 @@ def ssim(img1, img2, window_size=11, size_average=True):
 
 
 def training_loss(image, gt_image, lambda_dssim=0.2):
-    """reference train.py:114-121"""
+    """reference train.py:114-121 with the pure-PyTorch ssim() (the FUSED_SSIM_AVAILABLE == False branch)."""
     Ll1 = l1_loss(image, gt_image)
     return (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt_image))
+
+
+def training_loss_fused(image, gt_image, lambda_dssim=0.2):
+    """reference train.py:114-121, FUSED_SSIM_AVAILABLE branch: `fused_ssim(image.unsqueeze(0), gt.unsqueeze(0))` runs in the
+    HIP kernels of csrc/ssim.hip (no CPU path)."""
+    from fused_ssim import fused_ssim
+    Ll1 = l1_loss(image, gt_image)
+    return (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - fused_ssim(image.unsqueeze(0), gt_image.unsqueeze(0)))

@@ -132,6 +132,28 @@ int gsr_debug_binning_views(const void* binning_state, int32_t image_width, int3
 int gsr_debug_image_views(const void* image_state, int32_t image_width, int32_t image_height,
                           const float** final_T, const uint32_t** n_contrib);
 
+/* ---- callers of the hot path that the reference also takes from native modules ---- */
+
+/* Fused SSIM map, 11x11 Gaussian window sigma 1.5, zero "same" padding (what reference utils/loss_utils.py:100-159
+ * computes; serves `_C.fusedssim` of utils/loss_utils.py:16-38 and `fused_ssim.fused_ssim` of train.py:31-35,116-117).
+ * img*, maps: [planes,H,W].  The three dm_* maps (all NULL or all non-NULL) are what the backward needs. */
+int gsr_fused_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float C2, const float* img1,
+                           const float* img2, float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq,
+                           float* dm_dsigma12, void* stream);
+int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2,
+                            const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                            const float* dm_dsigma12, float* dL_dimg1, void* stream);
+
+/* One-launch Adam over up to 8 tensors.  Dense = torch.optim.Adam semantics (reference scene/gaussian_model.py:169-170
+ * default optimizer); sparse = `SparseGaussianAdam.step(visibility, N)` (reference train.py:37-41,173-176): rows of
+ * invisible Gaussians untouched, no bias correction.  Array arguments are HOST arrays of `count` entries. */
+int gsr_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, float beta1,
+                  float beta2, float eps, void* stream);
+int gsr_sparse_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                         float* const* exp_avg_sq, const int64_t* numel, const float* lr, int64_t N,
+                         const uint8_t* visible, float beta1, float beta2, float eps, void* stream);
+
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline block). */
 void gsr_profile_enable(int32_t on);
 void gsr_profile_reset(void);

@@ -1,0 +1,106 @@
+"""world_size-2 gloo tests of the view-sharded data-parallel path on CPU.  The renderer injected into
+the Trainer here is the CPU oracle (tests may use it); the sharding / bucketed all-reduce / statistics logic is the
+product code that bench.py runs over RCCL."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_render(cam, pc, pipe, bg, **kw):
+    from oracle import gs_oracle as O
+    m2d = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
+    m2d.retain_grad()
+    s = O.OracleSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg,
+                         1.0, cam.world_view_transform, cam.full_proj_transform, pc.active_sh_degree,
+                         cam.camera_center, False, False, False)
+    color, radii, invd = O.rasterize(pc.get_xyz, m2d, pc.get_opacity, s, shs=pc.get_features,
+                                     scales=pc.get_scaling, rotations=pc.get_rotation)
+    return {"render": color, "viewspace_points": m2d, "visibility_filter": radii > 0, "radii": radii, "depth": invd}
+
+
+def _scene():
+    from scene_utils import make_gaussians, fibonacci_cameras, GaussianModel
+    raw = make_gaussians(120, 1, seed=5, scale_factor=1.2)
+    cams = fibonacci_cameras(4, 32, 32, seed=6)
+    gts = {i: torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(100 + i)) for i in range(4)}
+    return raw, cams, gts
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from scene_utils import init_from_env, shard_views, Trainer, GaussianModel, reduce_densification_stats
+    from gaussian_renderer import PipelineParams
+    r, w, _ = init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    raw, cams, gts = _scene()
+    model = GaussianModel.from_raw(raw)
+    tr = Trainer(model, cams, gts, _oracle_render, PipelineParams(), torch.zeros(3), world=w, rank=r, optimizer="torch", loss="torch")
+    mine = shard_views(len(cams), r, w)
+    for v in mine[:1]:
+        tr.step(v)
+    reduce_densification_stats(tr.xyz_gradient_accum, tr.denom, tr.max_radii2D, w)
+    torch.save({"params": [p.detach().clone() for p in model.parameters()], "accum": tr.xyz_gradient_accum,
+                "denom": tr.denom, "maxr": tr.max_radii2D, "views": mine}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_views_partition():
+    from scene_utils import shard_views
+    for world in (1, 2, 3, 8):
+        parts = [shard_views(100, r, world) for r in range(world)]
+        flat = sorted(v for p in parts for v in p)
+        assert flat == list(range(100))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_equals_mean_gradient_step(tmp_path):
+    """After one DP step both ranks hold identical parameters, equal to a single-process Adam step on the MEAN of the two
+    per-view gradients; densification statistics are the SUM / MAX over views."""
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "r0.pt"))
+    b = torch.load(os.path.join(tmp_path, "r1.pt"))
+    assert a["views"] == [0, 2] and b["views"] == [1, 3]
+    for pa, pb in zip(a["params"], b["params"]):
+        assert torch.equal(pa, pb)
+    assert torch.equal(a["accum"], b["accum"]) and torch.equal(a["denom"], b["denom"]) and torch.equal(a["maxr"], b["maxr"])
+
+    # single-process reference of the same step
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-slam_amd"))
+    from scene_utils import GaussianModel, training_loss
+    from gaussian_renderer import PipelineParams
+    raw, cams, gts = _scene()
+    model = GaussianModel.from_raw(raw)
+    opt = torch.optim.Adam(model.param_groups(), lr=0.0, eps=1e-15)
+    grads = [torch.zeros_like(p) for p in model.parameters()]
+    accum = torch.zeros(120, 1); denom = torch.zeros(120, 1); maxr = torch.zeros(120)
+    for v in (0, 1):
+        pkg = _oracle_render(cams[v], model, PipelineParams(), torch.zeros(3))
+        loss = training_loss(pkg["render"], gts[v])
+        loss.backward()
+        vis = pkg["visibility_filter"]
+        accum[vis] += torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)
+        denom[vis] += 1
+        maxr[vis] = torch.max(maxr[vis], pkg["radii"][vis].float())
+        for g, p in zip(grads, model.parameters()):
+            g += p.grad
+            p.grad = None
+    for g, p in zip(grads, model.parameters()):
+        p.grad = g / 2
+    opt.step()
+    for pa, p in zip(a["params"], model.parameters()):
+        assert torch.allclose(pa, p.detach(), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(a["accum"], accum, atol=1e-6) and torch.equal(a["denom"], denom) and torch.equal(a["maxr"], maxr)

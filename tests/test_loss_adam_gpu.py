@@ -1,0 +1,96 @@
+"""GPU parity of the two callers of the hot path that the reference also takes from native modules:
+fused SSIM (oracle: the pure-PyTorch ssim() restated in scene_utils/losses.py, itself pinned against the reference's
+utils/loss_utils.py:ssim by tests/golden/reference_helpers.npz) and the one-launch Adam kernels (oracle: torch.optim.Adam
+on CPU; the sparse variant against a masked no-bias-correction restatement)."""
+import numpy as np
+import pytest
+import torch
+
+from scene_utils import losses
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(3, 40, 52), (1, 3, 67, 33), (3, 1080 // 4, 1920 // 4), (2, 3, 16, 16)])
+def test_fused_ssim_matches_reference_ssim(shape):
+    from fused_ssim import fused_ssim
+    gen = torch.Generator().manual_seed(sum(shape))
+    a = torch.rand(*shape, generator=gen, dtype=torch.float64)
+    b = (a + 0.1 * torch.randn(*shape, generator=gen, dtype=torch.float64)).clamp(0, 1)
+    a_ref = a.clone().requires_grad_(True)
+    val_ref = losses.ssim(a_ref, b)
+    val_ref.backward()
+    a_gpu = a.float().cuda().requires_grad_(True)
+    val = fused_ssim(a_gpu if a.dim() == 4 else a_gpu.unsqueeze(0), b.float().cuda() if a.dim() == 4 else b.float().cuda().unsqueeze(0))
+    val.backward()
+    assert abs(val.item() - val_ref.item()) <= 2e-6
+    g, g_ref = a_gpu.grad.cpu().double(), a_ref.grad
+    assert (g - g_ref).norm() / g_ref.norm() <= 1e-4
+    assert (g - g_ref).abs().max() <= 1e-4 * g_ref.abs().max() + 1e-9
+
+
+def test_fused_ssim_golden_and_interfaces():
+    """Value against the reference's own ssim() output (golden), and the `_C.fusedssim` / `fusedssim_backward` interface
+    of reference utils/loss_utils.py:16-38."""
+    import os
+    from diff_gaussian_rasterization._C import fusedssim, fusedssim_backward
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_helpers.npz"))
+    a, b = torch.tensor(G["img_a2"]).cuda(), torch.tensor(G["img_b2"]).cuda()
+    m = fusedssim(0.01 ** 2, 0.03 ** 2, a, b)
+    assert m.shape == a.shape
+    assert abs(m.mean().item() - float(G["ssim_ab2"])) <= 2e-6
+    g = fusedssim_backward(0.01 ** 2, 0.03 ** 2, a, b, torch.full_like(a, 1.0 / a.numel()))
+    a_ref = torch.tensor(G["img_a2"], dtype=torch.float64, requires_grad=True)
+    losses.ssim(a_ref, torch.tensor(G["img_b2"], dtype=torch.float64)).backward()
+    assert (g.cpu().double() - a_ref.grad).norm() / a_ref.grad.norm() <= 1e-4
+
+
+def test_fused_adam_matches_torch_adam():
+    from diff_gaussian_rasterization import FusedAdam
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(1001, 3), (1001, 1, 3), (1001, 15, 3), (1001, 1), (1001, 3), (1001, 4)]
+    lrs = [0.00016, 0.0025, 0.000125, 0.025, 0.005, 0.001]
+    ref = [torch.randn(*s, generator=gen).requires_grad_(True) for s in shapes]
+    dev = [r.detach().clone().cuda().requires_grad_(True) for r in ref]
+    o_ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref, lrs)], lr=0.0, eps=1e-15)
+    o_dev = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(dev, lrs)], lr=0.0, eps=1e-15)
+    for it in range(5):
+        for r, d in zip(ref, dev):
+            g = torch.randn(*r.shape, generator=gen) * (10.0 ** torch.randint(-6, 1, (1,), generator=gen).item())
+            r.grad = g.clone()
+            d.grad = g.clone().cuda()
+        o_ref.step()
+        o_dev.step()
+    for r, d in zip(ref, dev):
+        assert torch.allclose(d.detach().cpu(), r.detach(), rtol=2e-6, atol=1e-7)
+    st = o_dev.state[dev[2]]
+    assert torch.allclose(st["exp_avg_sq"].cpu(), o_ref.state[ref[2]]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+
+
+def test_sparse_adam_touches_only_visible_rows():
+    from diff_gaussian_rasterization import SparseGaussianAdam
+    gen = torch.Generator().manual_seed(1)
+    N = 777
+    shapes = [(N, 3), (N, 1, 3), (N, 15, 3), (N, 1), (N, 3), (N, 4)]
+    ps = [torch.randn(*s, generator=gen) for s in shapes]
+    dev = [p.clone().cuda().requires_grad_(True) for p in ps]
+    opt = SparseGaussianAdam([{"params": [p], "lr": 0.01 * (i + 1)} for i, p in enumerate(dev)], lr=0.0, eps=1e-15)
+    vis = torch.rand(N, generator=gen) < 0.6
+    m = [torch.zeros_like(p) for p in ps]
+    v = [torch.zeros_like(p) for p in ps]
+    cur = [p.clone() for p in ps]
+    for it in range(3):
+        gs = [torch.randn(*p.shape, generator=gen) for p in ps]
+        for d, g in zip(dev, gs):
+            d.grad = g.cuda()
+        opt.step(vis.cuda(), N)
+        for i, g in enumerate(gs):
+            mask = vis.view(N, *([1] * (g.dim() - 1))).expand_as(g)
+            m_new = 0.9 * m[i] + 0.1 * g
+            v_new = 0.999 * v[i] + 0.001 * g * g
+            upd = cur[i] - 0.01 * (i + 1) * m_new / (v_new.sqrt() + 1e-15)
+            m[i] = torch.where(mask, m_new, m[i]); v[i] = torch.where(mask, v_new, v[i]); cur[i] = torch.where(mask, upd, cur[i])
+    for d, c, p0 in zip(dev, cur, ps):
+        assert torch.allclose(d.detach().cpu(), c, rtol=2e-6, atol=1e-7)
+        inv = ~vis
+        assert torch.equal(d.detach().cpu()[inv], p0[inv])       # invisible rows bit-identical
