@@ -92,8 +92,8 @@ extern "C" {
 // Dense Adam step (torch.optim.Adam semantics, amsgrad/weight_decay/maximize off) on `count` tensors in one launch.
 // step[i] is the 1-based step number of tensor i AFTER this update (used for the bias corrections).
 int gsr_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
-                  float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, float beta1,
-                  float beta2, float eps, void* stream) {
+                  float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, double beta1,
+                  double beta2, double eps, void* stream) {
   if (count < 0 || count > GSR_ADAM_MAX_TENSORS) {
     gsr_set_error("adam: at most %d tensors per call", GSR_ADAM_MAX_TENSORS);
     return GSR_ERR_INVALID_ARGUMENT;
@@ -104,8 +104,8 @@ int gsr_adam_step(int32_t count, float* const* params, const float* const* grads
   for (int i = 0; i < count; i++) {
     b.p[i] = params[i]; b.g[i] = grads[i]; b.m[i] = exp_avg[i]; b.v[i] = exp_avg_sq[i];
     b.n[i] = numel[i]; b.row[i] = 1; b.lr[i] = lr[i];
-    const double bc1 = 1.0 - pow((double)beta1, (double)step[i]);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step[i]);
+    const double bc1 = 1.0 - pow(beta1, (double)step[i]);
+    const double bc2 = 1.0 - pow(beta2, (double)step[i]);
     b.step_size[i] = (float)((double)lr[i] / bc1);
     b.inv_bc2_sqrt[i] = (float)(1.0 / sqrt(bc2));
     b.block_begin[i] = blocks;
@@ -114,15 +114,15 @@ int gsr_adam_step(int32_t count, float* const* params, const float* const* grads
   b.block_begin[count] = blocks;
   if (blocks == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  GSR_LAUNCH("adam_dense", k_adam<false>, dim3(blocks), dim3(256), 0, st, b, beta1, beta2,
-             (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps, (const uint8_t*)nullptr);
+  GSR_LAUNCH("adam_dense", k_adam<false>, dim3(blocks), dim3(256), 0, st, b, (float)beta1, (float)beta2,
+             (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (const uint8_t*)nullptr);
   return gsr_check(hipGetLastError(), "adam launch");
 }
 
 // Sparse (visibility-masked) Adam: tensor i has N rows of numel[i]/N elements; rows with visible[row]==0 are untouched.
 int gsr_sparse_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                          float* const* exp_avg_sq, const int64_t* numel, const float* lr, int64_t N,
-                         const uint8_t* visible, float beta1, float beta2, float eps, void* stream) {
+                         const uint8_t* visible, double beta1, double beta2, double eps, void* stream) {
   if (count < 0 || count > GSR_ADAM_MAX_TENSORS || N <= 0 || !visible) {
     gsr_set_error("sparse adam: bad arguments");
     return GSR_ERR_INVALID_ARGUMENT;
@@ -145,8 +145,8 @@ int gsr_sparse_adam_step(int32_t count, float* const* params, const float* const
   b.block_begin[count] = blocks;
   if (blocks == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  GSR_LAUNCH("adam_sparse", k_adam<true>, dim3(blocks), dim3(256), 0, st, b, beta1, beta2,
-             (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps, visible);
+  GSR_LAUNCH("adam_sparse", k_adam<true>, dim3(blocks), dim3(256), 0, st, b, (float)beta1, (float)beta2,
+             (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, visible);
   return gsr_check(hipGetLastError(), "sparse adam launch");
 }
 

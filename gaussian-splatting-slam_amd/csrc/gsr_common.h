@@ -16,8 +16,9 @@
 // -------------------------------------------------------------------------------------------------
 // Packed per-Gaussian splat record written by preprocess and staged through LDS by the render kernels:
 //   r0 = (mean2D.x, mean2D.y, conic.A, conic.B)
-//   r1 = (conic.C, opacity*aa, rgb.r, rgb.g)
-//   r2 = (rgb.b, 1/depth, depth, unused)
+//   r1 = (conic.C, opacity*aa, pmin = -ln(255 opacity*aa) - margin, rgb.r)
+//   r2 = (rgb.g, rgb.b, 1/depth, depth)
+// r0 + r1 are all a wave needs to reject a Gaussian for its 64 pixels; r2 is read on hits only.
 // One 48-B gather per (tile, instance) instead of four separate arrays.
 // -------------------------------------------------------------------------------------------------
 

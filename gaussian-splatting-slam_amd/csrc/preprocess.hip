@@ -229,9 +229,12 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
           }
         }
         const float op = opacities[idx] * h;
+        // conservative cut-off for the render kernels: alpha = op*exp(power) >= 1/255  <=>  power >= -ln(255 op);
+        // the margin (>> fp32 error of power / exp) keeps the test a pure accelerator (exact test follows it)
+        const float pmin = (op > 0.f) ? (-logf(255.0f * op) - 0.01f) : 1.0f;
         rec[3 * (size_t)idx + 0] = make_float4(px, py, cA, cB);
-        rec[3 * (size_t)idx + 1] = make_float4(cC, op, rgb[0], rgb[1]);
-        rec[3 * (size_t)idx + 2] = make_float4(rgb[2], 1.0f / t[2], t[2], 0.f);
+        rec[3 * (size_t)idx + 1] = make_float4(cC, op, pmin, rgb[0]);
+        rec[3 * (size_t)idx + 2] = make_float4(rgb[1], rgb[2], 1.0f / t[2], t[2]);
         rect[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
         clamped[idx] = cl;
         out_radius = (int32_t)radius;
@@ -287,8 +290,27 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 #pragma unroll
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
     const uint32_t s0 = slot_start[idx], n = tiles_touched[idx];
-    for (uint32_t e = 0; e < n; e++) {
-      const size_t pos = pos_of_slot[s0 + e];
+    // 4 independent (index -> 48-B record) chains in flight per thread: the loop is latency-bound otherwise.
+    // Summation order stays slot order (deterministic).
+    uint32_t it = 0;
+    for (; it + 4 <= n; it += 4) {
+      size_t pos[4];
+      float4 q[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; u++) pos[u] = pos_of_slot[s0 + it + u];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        q[u][0] = igrad[3 * pos[u] + 0]; q[u][1] = igrad[3 * pos[u] + 1]; q[u][2] = igrad[3 * pos[u] + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        acc[0] += q[u][0].x; acc[1] += q[u][0].y; acc[2] += q[u][0].z; acc[3] += q[u][0].w;
+        acc[4] += q[u][1].x; acc[5] += q[u][1].y; acc[6] += q[u][1].z; acc[7] += q[u][1].w;
+        acc[8] += q[u][2].x; acc[9] += q[u][2].y;
+      }
+    }
+    for (; it < n; it++) {
+      const size_t pos = pos_of_slot[s0 + it];
       const float4 r0 = igrad[3 * pos + 0], r1 = igrad[3 * pos + 1], r2 = igrad[3 * pos + 2];
       acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
       acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;

@@ -3,7 +3,9 @@
 // MI355X mapping: one 256-thread workgroup (4 wave64) per tile; wave w owns the 8x8 pixel quadrant w, lane l
 // the pixel (l&7, l>>3) of it, so a Gaussian that misses a quadrant is rejected for 64 pixels by ONE
 // wave-uniform ballot + branch.  Batches of 256 packed 48-B splat records are staged through LDS (one
-// coalesced gather per record) and read back as wave-uniform broadcasts (conflict-free).
+// coalesced gather per record) and read back as wave-uniform broadcasts (conflict-free), software-prefetched one
+// entry ahead.  A conservative wave-level test `power >= -ln(255 opacity) - margin` rejects a Gaussian for a whole
+// quadrant before the exp; survivors take the exact published test, so results are unchanged.
 //
 // Backward: per-pixel back-to-front replay as published (T recovered by division), but NO global atomics:
 // each wave reduces its 64 pixels' contributions with a DPP scan (6 VALU/value), lane 63 adds the wave total
@@ -13,12 +15,45 @@
 
 #define ALPHA_MIN (1.0f / 255.0f)
 
+// In-place full-wave sums of ten registers; totals valid in lane 63.  gfx9 DPP: a lane whose DPP source is out of
+// range (bound_ctrl:0) or whose row is masked keeps its value, so `v_add_f32_dpp v, v, v <ctrl>` accumulates in place
+// with no v_mov.  Steps are interleaved over the ten values so no instruction reads a register written by one of
+// the two preceding instructions (VALU-write -> DPP-read needs 2 wait states; hipcc pads nothing inside asm).
+#define GSR_DPP10(ctrl)                                   \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                   \
+  "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                   \
+  "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                   \
+  "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                   \
+  "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                   \
+  "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                   \
+  "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                   \
+  "v_add_f32_dpp %7, %7, %7 " ctrl "\n"                   \
+  "v_add_f32_dpp %8, %8, %8 " ctrl "\n"                   \
+  "v_add_f32_dpp %9, %9, %9 " ctrl "\n"
+
+__device__ __forceinline__ void wave_sum10_to_lane63(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5,
+                                                     float& v6, float& v7, float& v8, float& v9) {
+  asm volatile(
+      "s_nop 1\n"
+      GSR_DPP10("row_shr:1 row_mask:0xf bank_mask:0xf")
+      GSR_DPP10("row_shr:2 row_mask:0xf bank_mask:0xf")
+      GSR_DPP10("row_shr:4 row_mask:0xf bank_mask:0xf")
+      GSR_DPP10("row_shr:8 row_mask:0xf bank_mask:0xf")
+      GSR_DPP10("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      GSR_DPP10("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "s_nop 1\n"
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
+}
+
+#define FWD_BATCH 256
+#define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
+
 __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                                                     const uint32_t* __restrict__ point_list,
                                                     const float4* __restrict__ rec, const float* __restrict__ bg,
                                                     float* __restrict__ out_color, float* __restrict__ out_invdepth,
                                                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-  __shared__ float4 s0[256], s1[256], s2[256];
+  __shared__ float4 s0[FWD_BATCH + 2], s1[FWD_BATCH + 2], s2[FWD_BATCH + 2];  // +2: the prefetch may touch [n+1]
   const int tile = blockIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -28,15 +63,18 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   const float pxf = (float)px, pyf = (float)py;
   const uint2 range = ranges[tile];
   int toDo = (int)(range.y - range.x);
-  const int rounds = (toDo + 255) / 256;
+  const int rounds = (toDo + FWD_BATCH - 1) / FWD_BATCH;
 
   bool done = !inside;
+  // A finished (or outside) pixel is moved far away: its power becomes hugely negative and fails the wave-level
+  // reject test with no extra instruction in the loop.
+  float pxe = done ? 1.0e15f : pxf;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   uint32_t last = 0;
 
-  for (int r = 0; r < rounds; r++, toDo -= 256) {
+  for (int r = 0; r < rounds; r++, toDo -= FWD_BATCH) {
     if (__syncthreads_count(done) == 256) break;
-    const uint32_t progress = range.x + (uint32_t)(r * 256 + tid);
+    const uint32_t progress = range.x + (uint32_t)(r * FWD_BATCH + tid);
     if (progress < range.y) {
       const size_t id = point_list[progress];
       s0[tid] = rec[3 * id + 0];
@@ -44,31 +82,40 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
       s2[tid] = rec[3 * id + 2];
     }
     __syncthreads();
-    const int n = toDo < 256 ? toDo : 256;
-    for (int j = 0; j < n; j++) {
-      if (__ballot(!done) == 0ull) break;  // whole quadrant saturated
-      const float4 a = s0[j];
-      const float4 b = s1[j];
-      const float dx = a.x - pxf, dy = a.y - pyf;
+    const int n = toDo < FWD_BATCH ? toDo : FWD_BATCH;
+    bool wave_live = BALLOT(!done) != 0ull;
+    // one list entry against this wave's 64 pixels
+    auto step = [&](const float4& a, const float4& b, const int j) __attribute__((always_inline)) {
+      const float dx = a.x - pxe, dy = a.y - pyf;
       const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      const float alpha = fminf(0.99f, b.y * __expf(power));
-      const bool ok = !done && power <= 0.0f && alpha >= ALPHA_MIN;
-      if (__ballot(ok) == 0ull) continue;  // Gaussian misses this quadrant
-      if (ok) {
+      // conservative wave-level reject (b.z = -ln(255 opacity) - margin): no lane can reach alpha >= 1/255
+      if (BALLOT(power >= b.z) != 0ull) {
+        const float alpha = fminf(0.99f, b.y * __expf(power));
+        const bool ok = !done && power <= 0.0f && alpha >= ALPHA_MIN;
+        const float4 c = s2[j];
         const float test_T = T * (1.0f - alpha);
-        if (test_T < 0.0001f) {
-          done = true;  // the stopping Gaussian is NOT blended (A.5)
-        } else {
-          const float4 c = s2[j];
-          const float wgt = alpha * T;
-          C0 += b.z * wgt;
-          C1 += b.w * wgt;
-          C2 += c.x * wgt;
-          D += c.y * wgt;
-          T = test_T;
-          last = (uint32_t)(r * 256 + j + 1);
-        }
+        const bool stop = ok && test_T < 0.0001f;    // the stopping Gaussian is NOT blended (A.5)
+        const bool blend = ok && !stop;
+        const float wgt = blend ? alpha * T : 0.f;
+        C0 += b.w * wgt;
+        C1 += c.x * wgt;
+        C2 += c.y * wgt;
+        D += c.z * wgt;
+        T = blend ? test_T : T;
+        last = blend ? (uint32_t)(r * FWD_BATCH + j + 1) : last;
+        done = done || stop;
+        pxe = done ? 1.0e15f : pxf;
+        wave_live = BALLOT(!done) != 0ull;           // `done` only changes here: whole quadrant saturated -> leave
       }
+    };
+    // software prefetch, two register sets in ping-pong (entry j+1 / j+2 in flight while j / j+1 is evaluated)
+    float4 a0 = s0[0], b0 = s1[0];
+    for (int j = 0; j < n && wave_live; j += 2) {
+      const float4 a1 = s0[j + 1], b1 = s1[j + 1];
+      step(a0, b0, j);
+      a0 = s0[j + 2];
+      b0 = s1[j + 2];
+      if (j + 1 < n && wave_live) step(a1, b1, j + 1);
     }
   }
   if (inside) {
@@ -92,7 +139,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
                                                     const uint32_t* __restrict__ n_contrib,
                                                     const float* __restrict__ dL_dpix,
                                                     const float* __restrict__ dL_dinvdepth, float4* __restrict__ igrad) {
-  __shared__ float4 s0[BWD_BATCH], s1[BWD_BATCH], s2[BWD_BATCH];
+  __shared__ float4 s0[BWD_BATCH + 2], s1[BWD_BATCH + 2], s2[BWD_BATCH + 2];
   // one private slab per wave: no LDS atomics, and the 4 partial sums are added in a FIXED order at flush time,
   // so gradients are bitwise reproducible
   __shared__ float4 slab[4][BWD_BATCH * GSR_IGRAD_F4];
@@ -120,7 +167,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
     gp2 = dL_dpix[2 * N + pix];
     if (dL_dinvdepth) gd = dL_dinvdepth[pix];
   }
-  const float bg_dot = bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2;
+  const float neg_Tf_bg = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
 
   // entries beyond the deepest contributor of any pixel are never visited
   if (tid == 0) s_max = 0;
@@ -160,52 +207,56 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
     for (int i = 0; i < (BWD_BATCH * GSR_IGRAD_F4) / 64; i++) myslab[i * 64 + lane] = z4;
     __syncthreads();
     const int n = min(BWD_BATCH, toDo - b * BWD_BATCH);
-    for (int j = 0; j < n; j++) {
+    auto step = [&](const float4& a, const float4& bb, const int j) __attribute__((always_inline)) {
       const int entry1 = toDo - (b * BWD_BATCH + j);  // 1-based list position of this entry
-      const float4 a = s0[j];
-      const float4 bb = s1[j];
       const float dx = a.x - pxf, dy = a.y - pyf;
       const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+      const bool pre = entry1 <= last && power >= bb.z;   // conservative wave-level reject (see forward)
+      if (BALLOT(pre) == 0ull) return;
       const float G = __expf(power);
       const float alpha = fminf(0.99f, bb.y * G);
-      const bool ok = entry1 <= last && power <= 0.0f && alpha >= ALPHA_MIN;
-      if (__ballot(ok) == 0ull) continue;
+      const bool ok = pre && power <= 0.0f && alpha >= ALPHA_MIN;
+      if (BALLOT(ok) == 0ull) return;
       const float4 c = s2[j];
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
-      if (ok) {
-        T = T / (1.0f - alpha);
-        const float dch = alpha * T;
-        float dL_dalpha;
-        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = bb.z;
-        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = bb.w;
-        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c.x;
-        ad = last_alpha * ld + (1.f - last_alpha) * ad;    ld = c.y;
-        dL_dalpha = (bb.z - ar0) * gp0 + (bb.w - ar1) * gp1 + (c.x - ar2) * gp2 + (c.y - ad) * gd;
-        v6 = dch * gp0; v7 = dch * gp1; v8 = dch * gp2; v9 = dch * gd;
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-        const float dL_dG = bb.y * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddelx = -gdx * a.z - gdy * a.w;
-        const float dG_ddely = -gdy * bb.x - gdx * a.w;
-        v0 = dL_dG * dG_ddelx * halfW;
-        v1 = dL_dG * dG_ddely * halfH;
-        v2 = -0.5f * gdx * dx * dL_dG;
-        v3 = -gdx * dy * dL_dG;
-        v4 = -0.5f * gdy * dy * dL_dG;
-        v5 = G * dL_dalpha;
-      }
-      v0 = gsr_wave_sum_to_lane63(v0); v1 = gsr_wave_sum_to_lane63(v1);
-      v2 = gsr_wave_sum_to_lane63(v2); v3 = gsr_wave_sum_to_lane63(v3);
-      v4 = gsr_wave_sum_to_lane63(v4); v5 = gsr_wave_sum_to_lane63(v5);
-      v6 = gsr_wave_sum_to_lane63(v6); v7 = gsr_wave_sum_to_lane63(v7);
-      v8 = gsr_wave_sum_to_lane63(v8); v9 = gsr_wave_sum_to_lane63(v9);
+      // Lanes that do not blend this entry run the same arithmetic with alpha = G = 0: T, the "accumulated behind"
+      // recurrences and every gradient term then stay exactly unchanged / zero, so no per-lane branch is needed.
+      const float a_e = ok ? alpha : 0.f;
+      const float G_e = ok ? G : 0.f;
+      const float rcp = __builtin_amdgcn_rcpf(1.0f - a_e);
+      T = T * rcp;
+      const float dch = a_e * T;
+      ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = bb.w;
+      ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = c.x;
+      ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c.y;
+      ad = last_alpha * ld + (1.f - last_alpha) * ad;    ld = c.z;
+      last_alpha = a_e;
+      float dL_dalpha = (bb.w - ar0) * gp0 + (c.x - ar1) * gp1 + (c.y - ar2) * gp2 + (c.z - ad) * gd;
+      dL_dalpha = dL_dalpha * T + neg_Tf_bg * rcp;
+      float v6 = dch * gp0, v7 = dch * gp1, v8 = dch * gp2, v9 = dch * gd;
+      const float dL_dG = bb.y * dL_dalpha;
+      const float gdx = G_e * dx, gdy = G_e * dy;
+      const float dG_ddelx = -gdx * a.z - gdy * a.w;
+      const float dG_ddely = -gdy * bb.x - gdx * a.w;
+      float v0 = dL_dG * dG_ddelx * halfW;
+      float v1 = dL_dG * dG_ddely * halfH;
+      float v2 = -0.5f * gdx * dx * dL_dG;
+      float v3 = -gdx * dy * dL_dG;
+      float v4 = -0.5f * gdy * dy * dL_dG;
+      float v5 = G_e * dL_dalpha;
+      wave_sum10_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
       if (lane == 63) {
         myslab[3 * j + 0] = make_float4(v0, v1, v2, v3);
         myslab[3 * j + 1] = make_float4(v4, v5, v6, v7);
         myslab[3 * j + 2] = make_float4(v8, v9, 0.f, 0.f);
       }
+    };
+    float4 a0 = s0[0], b0 = s1[0];
+    for (int j = 0; j < n; j += 2) {
+      const float4 a1 = s0[j + 1], b1 = s1[j + 1];
+      step(a0, b0, j);
+      a0 = s0[j + 2];
+      b0 = s1[j + 2];
+      if (j + 1 < n) step(a1, b1, j + 1);
     }
     __syncthreads();
     // flush: 128 entries x 3 float4 = 384 float4, fixed summation order over the 4 waves

@@ -69,9 +69,9 @@ EXPORTS = {
     "gsr_fused_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),
     "gsr_fused_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
     "gsr_adam_step": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+                                C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "gsr_sparse_adam_step": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                        C.c_void_p]),
     "gsr_profile_enable": (None, [C.c_int32]),
     "gsr_profile_reset": (None, []),

@@ -50,9 +50,11 @@ class Trainer:
         loss.backward()
         with torch.no_grad():
             # densification statistics are per-view: norm BEFORE any cross-rank reduction
-            self.max_radii2D[vis] = torch.max(self.max_radii2D[vis], radii[vis].float())
-            self.xyz_gradient_accum[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)
-            self.denom[vis] += 1
+            # same values as reference train.py:159-160 / gaussian_model.py:431-433, written without boolean-mask
+            # indexing (which costs a device->host sync per step): radii and the gradient are 0 where not visible
+            torch.maximum(self.max_radii2D, radii.float(), out=self.max_radii2D)
+            self.xyz_gradient_accum += torch.norm(vsp.grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
+            self.denom += vis[:, None]
             if self.bucket is not None:
                 self.bucket.all_reduce_mean(self.world)
             if self.optimizer_kind == "hip_sparse":

@@ -146,13 +146,14 @@ int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* i
 
 /* One-launch Adam over up to 8 tensors.  Dense = torch.optim.Adam semantics (reference scene/gaussian_model.py:169-170
  * default optimizer); sparse = `SparseGaussianAdam.step(visibility, N)` (reference train.py:37-41,173-176): rows of
- * invisible Gaussians untouched, no bias correction.  Array arguments are HOST arrays of `count` entries. */
+ * invisible Gaussians untouched, no bias correction.  Array arguments are HOST arrays of `count` entries; betas / eps are
+ * doubles so that 1-beta is formed in double like torch does (1.f-0.999f is off by 1.3e-5 relative). */
 int gsr_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
-                  float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, float beta1,
-                  float beta2, float eps, void* stream);
+                  float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, double beta1,
+                  double beta2, double eps, void* stream);
 int gsr_sparse_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                          float* const* exp_avg_sq, const int64_t* numel, const float* lr, int64_t N,
-                         const uint8_t* visible, float beta1, float beta2, float eps, void* stream);
+                         const uint8_t* visible, double beta1, double beta2, double eps, void* stream);
 
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline block). */
 void gsr_profile_enable(int32_t on);

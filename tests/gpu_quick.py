@@ -32,7 +32,7 @@ def main():
     print(" n_contrib mismatch", int((ll["n_contrib"] != st["n_contrib"]).sum()), " final_T maxdiff", float((ll["final_T"].double()-st["final_T"]).abs().max()))
     # bit-exact binning check against keys built from the GPU's own depth bits / rects
     order = ll["order"]; tt = ll["tiles_touched"]; rect = ll["rect"].astype(np.int64)
-    depth_bits = ll["rec"][:, 10].numpy().view(np.uint32).astype(np.uint64)
+    depth_bits = ll["rec"][:, 11].numpy().view(np.uint32).astype(np.uint64)
     gx = (W + 15) // 16
     keys = []; ids = []
     for g in range(P):

@@ -62,7 +62,8 @@ def test_fused_adam_matches_torch_adam():
         o_ref.step()
         o_dev.step()
     for r, d in zip(ref, dev):
-        assert torch.allclose(d.detach().cpu(), r.detach(), rtol=2e-6, atol=1e-7)
+        err = (d.detach().cpu() - r.detach()).abs().max().item()
+        assert torch.allclose(d.detach().cpu(), r.detach(), rtol=2e-6, atol=1e-7), err
     st = o_dev.state[dev[2]]
     assert torch.allclose(st["exp_avg_sq"].cpu(), o_ref.state[ref[2]]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
 
@@ -91,6 +92,7 @@ def test_sparse_adam_touches_only_visible_rows():
             upd = cur[i] - 0.01 * (i + 1) * m_new / (v_new.sqrt() + 1e-15)
             m[i] = torch.where(mask, m_new, m[i]); v[i] = torch.where(mask, v_new, v[i]); cur[i] = torch.where(mask, upd, cur[i])
     for d, c, p0 in zip(dev, cur, ps):
-        assert torch.allclose(d.detach().cpu(), c, rtol=2e-6, atol=1e-7)
+        err = (d.detach().cpu() - c).abs().max().item()
+        assert torch.allclose(d.detach().cpu(), c, rtol=2e-6, atol=1e-7), err
         inv = ~vis
         assert torch.equal(d.detach().cpu()[inv], p0[inv])       # invisible rows bit-identical

@@ -102,7 +102,7 @@ def test_binning_bit_exact_and_image_state():
     ll = lowlevel_forward(raw, cam, 3, bg)
     P = 5000
     tt, rect, order = ll["tiles_touched"], ll["rect"].astype(np.int64), ll["order"]
-    depth_bits = ll["rec"][:, 10].numpy().view(np.uint32).astype(np.uint64)
+    depth_bits = ll["rec"][:, 11].numpy().view(np.uint32).astype(np.uint64)
     vis = ll["radii"].numpy() > 0
     assert ((tt > 0) == vis).all()
     # depth order: sorted keys ascending, permutation of all ids, stable on ties
