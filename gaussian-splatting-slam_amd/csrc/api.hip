@@ -14,14 +14,15 @@
 void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&,
                                hipStream_t);
 void gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
-                               const GsrGeomLayout&, const uint32_t*, const float4*, const gsr_grads*, hipStream_t);
+                               const GsrGeomLayout&, const float4*, const gsr_grads*, hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
 void gsr_launch_emit(int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, hipStream_t);
-void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, bool, hipStream_t);
+void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
                            float*, float*, uint32_t*, hipStream_t);
 void gsr_launch_render_bwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*,
-                           const float*, const uint32_t*, const float*, const float*, float4*, hipStream_t);
+                           const float*, const uint32_t*, const float*, const float*, const uint32_t*, float4*,
+                           hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------
 // errors
@@ -122,6 +123,8 @@ static int tile_bits(int tiles) {
   while ((1 << b) < tiles) b++;
   return b;
 }
+// which ping-pong buffer holds the tile-sorted (key, slot) arrays: one swap per 8-bit pass
+static int tile_sort_result_buffer(int tiles) { return ((tile_bits(tiles) + GSR_RADIX_BITS - 1) / GSR_RADIX_BITS) & 1; }
 
 static int validate(const gsr_settings* s, const gsr_gaussians* g) {
   if (!s || !g) { gsr_set_error("null settings/gaussians"); return GSR_ERR_INVALID_ARGUMENT; }
@@ -252,10 +255,11 @@ int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geom
     const int where = gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a),
                                            (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.val_b),
                                            /*vals_iota=*/true, R, tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st);
+    if (where != tile_sort_result_buffer(tiles)) { gsr_set_error("internal: tile sort buffer parity"); return GSR_ERR_HIP; }
     if ((rc = debug_sync(s, st, "tile sort"))) return rc;
     const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
     const uint32_t* vs = (const uint32_t*)(bin + (where ? BL.val_b : BL.val_a));
-    gsr_launch_finalize((uint32_t)R, ks, vs, bin, BL, for_backward != 0, st);
+    gsr_launch_finalize((uint32_t)R, ks, vs, bin, BL, st);
     if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
   }
   gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + BL.point_list),
@@ -295,10 +299,11 @@ int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* r
   if (R > 0) {
     gsr_launch_render_bwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + BL.point_list),
                           (const float4*)(geom + GL.rec), (const float*)(img + IL.final_T),
-                          (const uint32_t*)(img + IL.n_contrib), dL_dcolor, dL_dinvdepth, igrad, st);
+                          (const uint32_t*)(img + IL.n_contrib), dL_dcolor, dL_dinvdepth,
+                          (const uint32_t*)(bin + (tile_sort_result_buffer(tiles) ? BL.val_b : BL.val_a)), igrad, st);
     if ((rc = debug_sync(s, st, "render backward"))) return rc;
   }
-  gsr_launch_preprocess_bwd(s, g, radii, geom, GL, (const uint32_t*)(bin + BL.pos_of_slot), igrad, grads, st);
+  gsr_launch_preprocess_bwd(s, g, radii, geom, GL, igrad, grads, st);
   if ((rc = debug_sync(s, st, "preprocess backward"))) return rc;
   return gsr_check(hipGetLastError(), "backward launch");
 }

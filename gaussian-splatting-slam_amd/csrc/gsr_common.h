@@ -42,10 +42,9 @@ struct GsrGeomLayout {
 
 struct GsrBinLayout {
   size_t key_a, key_b;   // u32[R] tile ids (ping-pong)
-  size_t val_a, val_b;   // u32[R] emission slots (ping-pong)
+  size_t val_a, val_b;   // u32[R] emission slots (ping-pong); the sorted one (slot of each position) is kept for the backward
   size_t gauss_of_slot;  // u32[R]
   size_t point_list;     // u32[R] Gaussian ids sorted by (tile, depth, id)
-  size_t pos_of_slot;    // u32[R] final position of each emission slot (backward)
   size_t ranges;         // uint2[tiles]
   size_t scan_tmp;
   size_t radix_tmp;
@@ -115,7 +114,6 @@ static inline GsrBinLayout gsr_bin_layout(size_t R, size_t tiles) {
   L.val_b = o;         o += gsr_align(R * 4);
   L.gauss_of_slot = o; o += gsr_align(R * 4);
   L.point_list = o;    o += gsr_align(R * 4);
-  L.pos_of_slot = o;   o += gsr_align(R * 4);
   L.ranges = o;        o += gsr_align(tiles * 8);
   L.scan_tmp = o;      o += gsr_align(gsr_scan_tmp_elems(R) * 4);
   L.radix_tmp = o;     o += gsr_align(gsr_radix_tmp_elems(R) * 4);

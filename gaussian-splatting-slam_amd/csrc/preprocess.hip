@@ -3,7 +3,7 @@
 //   k_preprocess_fwd : K1 of SURVEY.md 2.3 (near cull, projection, EWA covariance, dilation / AA,
 //                      conic, radius, tile rect, SH -> RGB) - writes the packed 48-B splat record.
 //   k_preprocess_bwd : K8 + K9 fused, preceded by a deterministic per-Gaussian gather-sum of the
-//                      per-instance gradient records written by the render backward (no float atomics:
+//                      per-instance gradient records written (grouped per Gaussian) by the render backward (no float atomics:
 //                      MI355X global float atomics hit 64 different rows at ~0.08 TB/s, plain stores +
 //                      a gather pass run at HBM rate and make the gradients bitwise reproducible).
 //   k_mark_visible   : K10.
@@ -264,8 +264,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float scale_modifier, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy, int antialiasing,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const uint32_t* __restrict__ tiles_touched,
-    const uint32_t* __restrict__ slot_start, const uint32_t* __restrict__ pos_of_slot,
-    const float4* __restrict__ igrad, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+    const uint32_t* __restrict__ slot_start, const float4* __restrict__ igrad, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_ddc, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dcov3D) {
@@ -290,28 +289,23 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 #pragma unroll
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
     const uint32_t s0 = slot_start[idx], n = tiles_touched[idx];
-    // 4 independent (index -> 48-B record) chains in flight per thread: the loop is latency-bound otherwise.
-    // Summation order stays slot order (deterministic).
+    // this Gaussian's records are contiguous (slot order): stream them, 4 records in flight per thread.
+    // Summation order = slot order (deterministic).
+    const float4* rows = igrad + (size_t)GSR_IGRAD_F4 * s0;
     uint32_t it = 0;
     for (; it + 4 <= n; it += 4) {
-      size_t pos[4];
-      float4 q[4][3];
+      float4 q[12];
 #pragma unroll
-      for (int u = 0; u < 4; u++) pos[u] = pos_of_slot[s0 + it + u];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        q[u][0] = igrad[3 * pos[u] + 0]; q[u][1] = igrad[3 * pos[u] + 1]; q[u][2] = igrad[3 * pos[u] + 2];
-      }
+      for (int u = 0; u < 12; u++) q[u] = rows[3 * (size_t)it + u];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        acc[0] += q[u][0].x; acc[1] += q[u][0].y; acc[2] += q[u][0].z; acc[3] += q[u][0].w;
-        acc[4] += q[u][1].x; acc[5] += q[u][1].y; acc[6] += q[u][1].z; acc[7] += q[u][1].w;
-        acc[8] += q[u][2].x; acc[9] += q[u][2].y;
+        acc[0] += q[3 * u].x; acc[1] += q[3 * u].y; acc[2] += q[3 * u].z; acc[3] += q[3 * u].w;
+        acc[4] += q[3 * u + 1].x; acc[5] += q[3 * u + 1].y; acc[6] += q[3 * u + 1].z; acc[7] += q[3 * u + 1].w;
+        acc[8] += q[3 * u + 2].x; acc[9] += q[3 * u + 2].y;
       }
     }
     for (; it < n; it++) {
-      const size_t pos = pos_of_slot[s0 + it];
-      const float4 r0 = igrad[3 * pos + 0], r1 = igrad[3 * pos + 1], r2 = igrad[3 * pos + 2];
+      const float4 r0 = rows[3 * (size_t)it + 0], r1 = rows[3 * (size_t)it + 1], r2 = rows[3 * (size_t)it + 2];
       acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
       acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
       acc[8] += r2.x; acc[9] += r2.y;
@@ -564,14 +558,14 @@ void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, in
 }
 
 void gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii,
-                               const char* geom, const GsrGeomLayout& L, const uint32_t* pos_of_slot,
-                               const float4* igrad, const gsr_grads* gr, hipStream_t st) {
+                               const char* geom, const GsrGeomLayout& L, const float4* igrad, const gsr_grads* gr,
+                               hipStream_t st) {
   const int P = g->P;
   GSR_LAUNCH("preprocess_bwd", k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, st, P, s->sh_degree,
              g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations,
              g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width,
              s->image_height, s->tanfovx, s->tanfovy, s->antialiasing, radii, (const uint8_t*)(geom + L.clamped),
-             (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), pos_of_slot, igrad,
+             (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), igrad,
              gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities,
              gr->dL_dscales, gr->dL_drotations, gr->dL_dcov3D);
 }

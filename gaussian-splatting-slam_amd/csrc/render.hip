@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
                                                     const float* __restrict__ final_T,
                                                     const uint32_t* __restrict__ n_contrib,
                                                     const float* __restrict__ dL_dpix,
-                                                    const float* __restrict__ dL_dinvdepth, float4* __restrict__ igrad) {
+                                                    const float* __restrict__ dL_dinvdepth,
+                                                    const uint32_t* __restrict__ slot_of_pos,
+                                                    float4* __restrict__ igrad) {
   __shared__ float4 s0[BWD_BATCH + 2], s1[BWD_BATCH + 2], s2[BWD_BATCH + 2];
   // one private slab per wave: no LDS atomics, and the 4 partial sums are added in a FIXED order at flush time,
   // so gradients are bitwise reproducible
@@ -181,8 +183,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
   __syncthreads();
   const int toDo = min(len, s_max);
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Gradient records are stored by EMISSION SLOT (slot_of_pos = the tile sort's value array), i.e. grouped per
+  // Gaussian, so the per-Gaussian sum in k_preprocess_bwd streams contiguous memory; the scattered 48-B stores here
+  // are fire-and-forget.
   for (int i = toDo + tid; i < len; i += 256) {
-    float4* dst = igrad + (size_t)GSR_IGRAD_F4 * (range.x + i);
+    float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + i];
     dst[0] = z4; dst[1] = z4; dst[2] = z4;
   }
 
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       r.z = ((a0.z + a1.z) + a2.z) + a3.z;
       r.w = ((a0.w + a1.w) + a2.w) + a3.w;
       const int e = toDo - 1 - (b * BWD_BATCH + j);
-      igrad[(size_t)GSR_IGRAD_F4 * (range.x + e) + part] = r;
+      igrad[(size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + e] + part] = r;
     }
   }
 }
@@ -283,8 +288,8 @@ void gsr_launch_render_fwd(const gsr_settings* s, int tiles, int grid_x, const u
 
 void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,
                            const uint32_t* point_list, const float4* rec, const float* final_T,
-                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dinvdepth, float4* igrad,
-                           hipStream_t st) {
+                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dinvdepth,
+                           const uint32_t* slot_of_pos, float4* igrad, hipStream_t st) {
   GSR_LAUNCH("render_bwd", k_render_bwd, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
-             ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, igrad);
+             ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
 }

@@ -2,8 +2,8 @@
 
 The reference is single-GPU (utils/general_utils.py:133 pins cuda:0; no collective anywhere).  Views are
 independent units: every rank holds the full Gaussian set, renders views {v : v mod world == rank} and the six
-leaf gradients (59 floats per Gaussian at SH degree 3) are summed with ONE flattened all-reduce per step
-(RCCL over xGMI when the backend is "nccl"), then divided by the world size.  Densification statistics are
+leaf gradients (59 floats per Gaussian at SH degree 3) are averaged in place by back-to-back all-reduces per step
+(RCCL over xGMI when the backend is "nccl").  Densification statistics are
 per-view quantities and are reduced separately (`reduce_densification_stats`).
 """
 from __future__ import annotations
@@ -39,39 +39,35 @@ def shard_views(n_views: int, rank: int, world: int, epoch_perm=None):
 
 
 class GradBucket:
-    """Flattens the gradients of `params` into one contiguous fp32 buffer for a single all-reduce."""
+    """Sums the gradients of `params` over ranks and leaves the MEAN in `.grad`.
+
+    The six leaf gradients are reduced IN PLACE, one collective each, issued back-to-back as async work (RCCL runs
+    them in order on its own stream; the small ones pipeline behind the 180 MB SH-rest tensor).  Flattening them into
+    one buffer would add a 236 MB copy-in and copy-out per step (~0.25 ms on MI355X, ~7 % of the step) for nothing:
+    the collective is bandwidth-bound on the xGMI links either way."""
 
     def __init__(self, params):
         self.params = list(params)
-        self.numel = sum(p.numel() for p in self.params)
-        p0 = self.params[0]
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
-        self.views = []
-        o = 0
-        for p in self.params:
-            self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
-
-    def resize_like_params(self):
-        if sum(p.numel() for p in self.params) != self.numel:
-            self.__init__(self.params)
 
     def all_reduce_mean(self, world: int, group=None):
-        """Sums the params' .grad over ranks and writes the mean back into .grad."""
         if world <= 1:
             return
-        for p, v in zip(self.params, self.views):
+        backend = dist.get_backend(group)
+        use_avg = backend == "nccl"                  # RCCL averages in the reduction; gloo has no AVG
+        works = []
+        for p in self.params:
             if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.mul_(1.0 / world)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+                p.grad = torch.zeros_like(p)
+            g = p.grad
+            if not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            works.append(dist.all_reduce(g, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, group=group,
+                                         async_op=True))
+        for w in works:
+            w.wait()
+        if not use_avg:
+            for p in self.params:
+                p.grad.mul_(1.0 / world)
 
 
 def reduce_densification_stats(xyz_gradient_accum, denom, max_radii2D, world: int, group=None):
