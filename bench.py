@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--cpu-tiles", type=int, default=64)
     ap.add_argument("--optimizer", default="hip", choices=["hip", "hip_sparse", "torch"])
     ap.add_argument("--loss", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--concat-sh", action="store_true",
+                    help="pass torch.cat(dc, rest) as shs (separate_sh=False); default mirrors reference train.py:106 with "
+                         "SparseGaussianAdam importable: separate_sh=True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
@@ -185,7 +188,7 @@ def main():
 
     model, cams, gts, my_views, pipe, bg, cfg, render = build_scene(args, device, rank, world)
     trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=args.optimizer,
-                      loss=args.loss)
+                      loss=args.loss, separate_sh=not args.concat_sh)
     P = cfg["P"]
     M = (cfg["deg"] + 1) ** 2
     W, H = cfg["W"], cfg["H"]
@@ -235,12 +238,12 @@ def main():
     # forward-only throughput (reference render.py:37-49 path: no_grad)
     with torch.no_grad():
         for _ in range(3):
-            render(cams[view_at(0)], model, pipe, bg)
+            render(cams[view_at(0)], model, pipe, bg, separate_sh=not args.concat_sh)
         torch.cuda.synchronize()
         nf = max(5, min(30, args.steps))
         t0 = time.perf_counter()
         for i in range(nf):
-            render(cams[view_at(i)], model, pipe, bg)
+            render(cams[view_at(i)], model, pipe, bg, separate_sh=not args.concat_sh)
         torch.cuda.synchronize()
         fwd_s = (time.perf_counter() - t0) / nf
     result["fwd_mpix_per_s"] = round(W * H / fwd_s / 1e6, 1)

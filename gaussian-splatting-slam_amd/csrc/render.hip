@@ -31,6 +31,31 @@
   "v_add_f32_dpp %8, %8, %8 " ctrl "\n"                   \
   "v_add_f32_dpp %9, %9, %9 " ctrl "\n"
 
+#define GSR_DPP9(ctrl)                                    \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                   \
+  "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                   \
+  "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                   \
+  "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                   \
+  "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                   \
+  "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                   \
+  "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                   \
+  "v_add_f32_dpp %7, %7, %7 " ctrl "\n"                   \
+  "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
+
+__device__ __forceinline__ void wave_sum9_to_lane63(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5,
+                                                    float& v6, float& v7, float& v8) {
+  asm volatile(
+      "s_nop 1\n"
+      GSR_DPP9("row_shr:1 row_mask:0xf bank_mask:0xf")
+      GSR_DPP9("row_shr:2 row_mask:0xf bank_mask:0xf")
+      GSR_DPP9("row_shr:4 row_mask:0xf bank_mask:0xf")
+      GSR_DPP9("row_shr:8 row_mask:0xf bank_mask:0xf")
+      GSR_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      GSR_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "s_nop 1\n"
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
+}
+
 __device__ __forceinline__ void wave_sum10_to_lane63(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5,
                                                      float& v6, float& v7, float& v8, float& v9) {
   asm volatile(
@@ -132,6 +157,9 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
 
 #define BWD_BATCH 128   // entries staged per round in the backward (4 per-wave gradient slabs must fit LDS)
 
+// DEPTH = false: no gradient arrives on the inverse-depth image (the usual training step): its recurrence and its
+// reduction are compiled out.
+template <bool DEPTH>
 __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                                                     const uint32_t* __restrict__ point_list,
                                                     const float4* __restrict__ rec, const float* __restrict__ bg,
@@ -167,7 +195,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
     gp0 = dL_dpix[pix];
     gp1 = dL_dpix[N + pix];
     gp2 = dL_dpix[2 * N + pix];
-    if (dL_dinvdepth) gd = dL_dinvdepth[pix];
+    if (DEPTH) gd = dL_dinvdepth[pix];
   }
   const float neg_Tf_bg = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
 
@@ -233,11 +261,12 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = bb.w;
       ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = c.x;
       ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c.y;
-      ad = last_alpha * ld + (1.f - last_alpha) * ad;    ld = c.z;
+      if (DEPTH) { ad = last_alpha * ld + (1.f - last_alpha) * ad; ld = c.z; }
       last_alpha = a_e;
-      float dL_dalpha = (bb.w - ar0) * gp0 + (c.x - ar1) * gp1 + (c.y - ar2) * gp2 + (c.z - ad) * gd;
+      float dL_dalpha = (bb.w - ar0) * gp0 + (c.x - ar1) * gp1 + (c.y - ar2) * gp2;
+      if (DEPTH) dL_dalpha += (c.z - ad) * gd;
       dL_dalpha = dL_dalpha * T + neg_Tf_bg * rcp;
-      float v6 = dch * gp0, v7 = dch * gp1, v8 = dch * gp2, v9 = dch * gd;
+      float v6 = dch * gp0, v7 = dch * gp1, v8 = dch * gp2, v9 = DEPTH ? dch * gd : 0.f;
       const float dL_dG = bb.y * dL_dalpha;
       const float gdx = G_e * dx, gdy = G_e * dy;
       const float dG_ddelx = -gdx * a.z - gdy * a.w;
@@ -248,7 +277,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       float v3 = -gdx * dy * dL_dG;
       float v4 = -0.5f * gdy * dy * dL_dG;
       float v5 = G_e * dL_dalpha;
-      wave_sum10_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
+      if (DEPTH) wave_sum10_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
+      else wave_sum9_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8);
       if (lane == 63) {
         myslab[3 * j + 0] = make_float4(v0, v1, v2, v3);
         myslab[3 * j + 1] = make_float4(v4, v5, v6, v7);
@@ -290,6 +320,10 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
                            const uint32_t* point_list, const float4* rec, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dinvdepth,
                            const uint32_t* slot_of_pos, float4* igrad, hipStream_t st) {
-  GSR_LAUNCH("render_bwd", k_render_bwd, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
-             ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
+  if (dL_dinvdepth)
+    GSR_LAUNCH("render_bwd", k_render_bwd<true>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height,
+               grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
+  else
+    GSR_LAUNCH("render_bwd", k_render_bwd<false>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height,
+               grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
 }

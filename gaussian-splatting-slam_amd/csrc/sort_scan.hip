@@ -137,8 +137,8 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 
 // ---------------------------------------------------------------------------------------------------
 // radix sort, 8-bit digits, stable.
-//   pass = k_radix_hist (per-chunk digit counts, table[digit][chunk]) -> exclusive scan of the table ->
-//          k_radix_scatter (re-read the chunk, stable rank by wave ballots, scatter).
+//   pass = k_radix_hist (per-chunk digit counts, table[digit][chunk]) -> k_radix_rowscan (per-digit exclusive scan
+//          over chunks + digit totals) -> k_radix_scatter (re-read the chunk, stable rank by wave ballots, scatter).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t* __restrict__ table,
                                                     size_t n, int shift, uint32_t mask, uint32_t nblk) {
@@ -155,15 +155,50 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__
   table[(size_t)threadIdx.x * nblk + blockIdx.x] = hist[threadIdx.x];
 }
 
+// One workgroup per digit: exclusive scan of that digit's per-chunk counts (row `d` of the table) in place, row total to
+// totals[d].  Replaces a 3-launch device-wide scan of the whole table; the 256-entry scan of the totals is redone by
+// every scatter workgroup in LDS (trivial) instead of costing a launch.
+__global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ table, uint32_t* __restrict__ totals,
+                                                       uint32_t nblk) {
+  __shared__ uint32_t lds4[4];
+  uint32_t* row = table + (size_t)blockIdx.x * nblk;
+  uint32_t carry = 0;
+  for (uint32_t c0 = 0; c0 < nblk; c0 += GSR_SCAN_CHUNK) {
+    const uint32_t base = c0 + threadIdx.x * GSR_SCAN_ITEMS;
+    uint32_t v[GSR_SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < GSR_SCAN_ITEMS; i++) {
+      v[i] = (base + i < nblk) ? row[base + i] : 0u;
+      s += v[i];
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan_u32(s, &tot, lds4) + carry;
+#pragma unroll
+    for (int i = 0; i < GSR_SCAN_ITEMS; i++) {
+      if (base + i < nblk) row[base + i] = run;
+      run += v[i];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                        const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                       const uint32_t* __restrict__ table_excl, size_t n, int shift,
+                                                       const uint32_t* __restrict__ table_excl,
+                                                       const uint32_t* __restrict__ totals, size_t n, int shift,
                                                        uint32_t mask, uint32_t nblk) {
   __shared__ uint32_t digit_base[GSR_RADIX_SIZE];
   __shared__ uint32_t wave_cnt[4][GSR_RADIX_SIZE];
+  __shared__ uint32_t lds4[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  digit_base[tid] = table_excl[(size_t)tid * nblk + blockIdx.x];
+  {
+    uint32_t tot;
+    const uint32_t digit_start = block_excl_scan_u32(totals[tid], &tot, lds4);   // keys with a smaller digit
+    digit_base[tid] = digit_start + table_excl[(size_t)tid * nblk + blockIdx.x];
+  }
 #pragma unroll
   for (int i = 0; i < 4; i++) wave_cnt[i][tid] = 0;
   __syncthreads();
@@ -213,9 +248,8 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
                          int bits, uint32_t* tmp, hipStream_t st) {
   if (n == 0 || bits <= 0) return 0;
   const uint32_t nblk = (uint32_t)gsr_radix_blocks(n);
-  const size_t tab = (size_t)GSR_RADIX_SIZE * nblk;
   uint32_t* table = tmp;
-  uint32_t* scan_tmp = tmp + gsr_align((GSR_RADIX_SIZE * ((size_t)nblk + 1)) * 4) / 4;
+  uint32_t* totals = tmp + (size_t)GSR_RADIX_SIZE * nblk;     // sized by gsr_radix_tmp_elems: 256 * (nblk + 1)
   int cur = 0;
   for (int shift = 0; shift < bits; shift += GSR_RADIX_BITS) {
     const int nb = (bits - shift) < GSR_RADIX_BITS ? (bits - shift) : GSR_RADIX_BITS;
@@ -227,9 +261,9 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
     const uint32_t* vin = (shift == 0 && vals_iota) ? nullptr : vi;
     GSR_LAUNCH("radix_hist", k_radix_hist, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, table, n, shift, mask,
                nblk);
-    gsr_scan_u32(table, nullptr, table, tab, 0, scan_tmp, st);
+    GSR_LAUNCH("radix_rowscan", k_radix_rowscan, dim3(GSR_RADIX_SIZE), dim3(256), 0, st, table, totals, nblk);
     GSR_LAUNCH("radix_scatter", k_radix_scatter, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin, ko, vo,
-               (const uint32_t*)table, n, shift, mask, nblk);
+               (const uint32_t*)table, (const uint32_t*)totals, n, shift, mask, nblk);
     cur ^= 1;
   }
   return cur;

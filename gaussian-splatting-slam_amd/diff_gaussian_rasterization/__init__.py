@@ -114,6 +114,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
                               geom, binning, img)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)     # an unused inverse-depth output reaches backward as None, not as zeros
         return color, radii, invdepth
 
     @staticmethod
@@ -127,6 +128,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = int(means3D.shape[0])
         H, W = int(rs.image_height), int(rs.image_width)
         grad_color = _f32c(grad_color) if grad_color is not None else torch.zeros(3, H, W, device=dev)
+        if grad_color is None:
+            grad_color = torch.zeros(3, H, W, device=dev)
         grad_invdepth = _f32c(grad_invdepth)
 
         def like(t, *shape):

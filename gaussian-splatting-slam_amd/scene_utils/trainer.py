@@ -11,7 +11,7 @@ from .parallel import GradBucket
 
 class Trainer:
     def __init__(self, model, cameras, gt_images, render_fn, pipe, bg, lambda_dssim=0.2, world=1, rank=0,
-                 optimizer="hip", loss="hip", depth_targets=None, depth_weight=0.0):
+                 optimizer="hip", loss="hip", depth_targets=None, depth_weight=0.0, separate_sh=False):
         """optimizer: "hip" (one-launch HIP Adam, default-optimizer semantics), "hip_sparse" (SparseGaussianAdam, the
         reference's accelerated choice) or "torch" (torch.optim.Adam; CPU tests).  loss: "hip" (fused SSIM kernels) or
         "torch" (pure-PyTorch ssim; CPU tests)."""
@@ -38,11 +38,13 @@ class Trainer:
         self.denom = torch.zeros(P, 1, device=dev)
         self.max_radii2D = torch.zeros(P, device=dev)
         self.depth_targets, self.depth_weight = depth_targets, depth_weight
+        # reference train.py:106 passes separate_sh=SPARSE_ADAM_AVAILABLE: dc / rest go to the rasterizer unconcatenated
+        self.separate_sh = separate_sh
         self.last = {}
 
     def step(self, view_idx: int):
         cam = self.cameras[view_idx]
-        pkg = self.render_fn(cam, self.model, self.pipe, self.bg)
+        pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh)
         image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
         loss = self.loss_fn(image, self.gt_images[view_idx], self.lambda_dssim)
         if self.depth_weight > 0 and self.depth_targets is not None:

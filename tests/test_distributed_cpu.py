@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _oracle_render(cam, pc, pipe, bg, **kw):
+def _oracle_render(cam, pc, pipe, bg, separate_sh=False, **kw):
     from oracle import gs_oracle as O
     m2d = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
     m2d.retain_grad()
