@@ -15,59 +15,71 @@
 
 #define ALPHA_MIN (1.0f / 255.0f)
 
-// In-place full-wave sums of ten registers; totals valid in lane 63.  gfx9 DPP: a lane whose DPP source is out of
-// range (bound_ctrl:0) or whose row is masked keeps its value, so `v_add_f32_dpp v, v, v <ctrl>` accumulates in place
-// with no v_mov.  Steps are interleaved over the ten values so no instruction reads a register written by one of
-// the two preceding instructions (VALU-write -> DPP-read needs 2 wait states; hipcc pads nothing inside asm).
-#define GSR_DPP10(ctrl)                                   \
-  "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                   \
-  "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                   \
-  "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                   \
-  "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                   \
-  "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                   \
-  "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                   \
-  "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                   \
-  "v_add_f32_dpp %7, %7, %7 " ctrl "\n"                   \
-  "v_add_f32_dpp %8, %8, %8 " ctrl "\n"                   \
-  "v_add_f32_dpp %9, %9, %9 " ctrl "\n"
+// ---------------------------------------------------------------------------------------------------------------
+// Ten full-wave sums by recursive halving: at every stage a lane keeps half of its values and hands the other half to
+// its partner, so the work per stage halves (10 -> 5 -> 3 -> 2 registers) instead of staying at ten DPP adds per stage.
+//   stage A  lanes l <-> l^32   v_permlane32_swap_b32 (gfx950): x'=[x.lo,y.lo] y'=[x.hi,y.hi]; x'+y' = [sum x | sum y]
+//   stage B  rows  r <-> r^1    v_permlane16_swap_b32 (gfx950): same idea on 16-lane rows
+//   stage C  lanes l <-> l^8    DPP row_ror:8 with a lane-bit select
+//   stage D-F                   quad_perm xor 1, xor 2, row_half_mirror: every lane of an 8-lane octet gets the octet sum
+// 27 VALU instead of 60.  Result: u0 in octet o = lane>>3 holds the total of value OCTET_VALUE[o] = {0,4,2,6,1,5,3,7}[o];
+// u1 holds the total of v8 in lanes 0..15 and of v9 in lanes 32..47.  The summation tree is fixed -> deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+typedef unsigned gsr_u2 __attribute__((ext_vector_type(2)));
 
-#define GSR_DPP9(ctrl)                                    \
-  "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                   \
-  "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                   \
-  "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                   \
-  "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                   \
-  "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                   \
-  "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                   \
-  "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                   \
-  "v_add_f32_dpp %7, %7, %7 " ctrl "\n"                   \
-  "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
-
-__device__ __forceinline__ void wave_sum9_to_lane63(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5,
-                                                    float& v6, float& v7, float& v8) {
-  asm volatile(
-      "s_nop 1\n"
-      GSR_DPP9("row_shr:1 row_mask:0xf bank_mask:0xf")
-      GSR_DPP9("row_shr:2 row_mask:0xf bank_mask:0xf")
-      GSR_DPP9("row_shr:4 row_mask:0xf bank_mask:0xf")
-      GSR_DPP9("row_shr:8 row_mask:0xf bank_mask:0xf")
-      GSR_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
-      GSR_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
-      "s_nop 1\n"
-      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
+__device__ __forceinline__ float swap32_add(float x, float y) {
+  const gsr_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float swap16_add(float x, float y) {
+  const gsr_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-__device__ __forceinline__ void wave_sum10_to_lane63(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5,
-                                                     float& v6, float& v7, float& v8, float& v9) {
-  asm volatile(
-      "s_nop 1\n"
-      GSR_DPP10("row_shr:1 row_mask:0xf bank_mask:0xf")
-      GSR_DPP10("row_shr:2 row_mask:0xf bank_mask:0xf")
-      GSR_DPP10("row_shr:4 row_mask:0xf bank_mask:0xf")
-      GSR_DPP10("row_shr:8 row_mask:0xf bank_mask:0xf")
-      GSR_DPP10("row_bcast:15 row_mask:0xa bank_mask:0xf")
-      GSR_DPP10("row_bcast:31 row_mask:0xc bank_mask:0xf")
-      "s_nop 1\n"
-      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
+__device__ __forceinline__ void wave_sum10_halving(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                                   float v7, float v8, float v9, bool lane_bit3, float& u0, float& u1) {
+  // A: 10 -> 5
+  const float r0 = swap32_add(v0, v1), r1 = swap32_add(v2, v3), r2 = swap32_add(v4, v5), r3 = swap32_add(v6, v7),
+              r4 = swap32_add(v8, v9);
+  // B: 5 -> 3   (rows: s0 = [v0,v2,v1,v3], s1 = [v4,v6,v5,v7], s2 = [v8,0,v9,0])
+  const float s0 = swap16_add(r0, r1), s1 = swap16_add(r2, r3), s2 = swap16_add(r4, 0.0f);
+  // C: 3 -> 2   (lanes with bit 3 clear keep s0, the others keep s1; each sends what it does not keep)
+  const float keep = lane_bit3 ? s1 : s0;
+  const float send = lane_bit3 ? s0 : s1;
+  float a = keep + dpp_get<0x128>(send);   // row_ror:8
+  float b = s2 + dpp_get<0x128>(s2);
+  // D-F: sum the 8 lanes of each octet
+  a += dpp_get<0xB1>(a);                   // quad_perm:[1,0,3,2]
+  b += dpp_get<0xB1>(b);
+  a += dpp_get<0x4E>(a);                   // quad_perm:[2,3,0,1]
+  b += dpp_get<0x4E>(b);
+  a += dpp_get<0x141>(a);                  // row_half_mirror
+  b += dpp_get<0x141>(b);
+  u0 = a;
+  u1 = b;
+}
+
+// test hook (tests/test_parity_gpu.py::test_wave_reduction_primitive): in[10][64] -> out[10] through the same store
+// pattern the render backward uses
+__global__ void k_debug_wave_reduce(const float* __restrict__ in, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  float u0, u1;
+  wave_sum10_halving(in[0 * 64 + lane], in[1 * 64 + lane], in[2 * 64 + lane], in[3 * 64 + lane], in[4 * 64 + lane],
+                     in[5 * 64 + lane], in[6 * 64 + lane], in[7 * 64 + lane], in[8 * 64 + lane], in[9 * 64 + lane],
+                     (lane & 8) != 0, u0, u1);
+  const int o = lane >> 3;
+  const int val = ((o & 1) << 2) | (o & 2) | ((o & 4) >> 2);   // {0,4,2,6,1,5,3,7}[o]
+  if ((lane & 7) == 0) out[val] = u0;
+  if ((lane & 31) == 0) out[8 + (lane >> 5)] = u1;
+}
+
+extern "C" int gsr_debug_wave_reduce(const float* in640, float* out10, void* stream) {
+  hipLaunchKernelGGL(k_debug_wave_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, in640, out10);
+  return gsr_check(hipGetLastError(), "debug wave reduce");
 }
 
 #define FWD_BATCH 256
@@ -225,6 +237,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
   float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f, last_alpha = 0.f;
   const float halfW = 0.5f * W, halfH = 0.5f * H;
   float4* myslab = slab[w];
+  const bool lane_bit3 = (lane & 8) != 0, octet_lead = (lane & 7) == 0, half_lead = (lane & 31) == 0;
+  const int octet_val = (((lane >> 3) & 1) << 2) | ((lane >> 3) & 2) | (((lane >> 3) & 4) >> 2);
 
   for (int b = 0; b < rounds; b++) {
     __syncthreads();
@@ -277,13 +291,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       float v3 = -gdx * dy * dL_dG;
       float v4 = -0.5f * gdy * dy * dL_dG;
       float v5 = G_e * dL_dalpha;
-      if (DEPTH) wave_sum10_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
-      else wave_sum9_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8);
-      if (lane == 63) {
-        myslab[3 * j + 0] = make_float4(v0, v1, v2, v3);
-        myslab[3 * j + 1] = make_float4(v4, v5, v6, v7);
-        myslab[3 * j + 2] = make_float4(v8, v9, 0.f, 0.f);
-      }
+      float u0, u1;
+      wave_sum10_halving(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, lane_bit3, u0, u1);
+      float* dst = reinterpret_cast<float*>(myslab) + 12 * j;
+      if (octet_lead) dst[octet_val] = u0;        // 8 lanes store v0..v7 totals
+      if (half_lead) dst[8 + (lane >> 5)] = u1;   // lanes 0 / 32 store v8 / v9
     };
     float4 a0 = s0[0], b0 = s1[0];
     for (int j = 0; j < n; j += 2) {

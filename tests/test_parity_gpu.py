@@ -307,3 +307,20 @@ def test_full_size_1080p_sampled_tiles_and_properties():
     assert torch.allclose(ll["color"][:, empty], bg[:, None].expand(3, int(empty.sum())))
     assert float(ll["final_T"].min()) >= 0 and float(ll["final_T"].max()) <= 1
     assert int(ll["ranges"][:, 1].max()) == ll["R"]
+
+
+def test_wave_reduction_primitive():
+    """The recursive-halving cross-lane reduction of the render backward (v_permlane32/16_swap + DPP) against exact sums:
+    integer-valued floats make every partial sum exact, so any lane-mapping mistake shows as a wrong integer."""
+    from diff_gaussian_rasterization import _C
+    lib = _C.lib()
+    gen = torch.Generator().manual_seed(4)
+    for trial in range(3):
+        x = torch.randint(-1000, 1000, (10, 64), generator=gen).float()
+        if trial == 0:
+            x = (torch.arange(640).view(10, 64) % 97).float() * (torch.arange(10).view(10, 1) + 1)
+        xin = x.cuda().contiguous()
+        out = torch.zeros(10, device="cuda")
+        _C.check(lib.gsr_debug_wave_reduce(_C.ptr(xin), _C.ptr(out), _C._stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), x.sum(dim=1)), (out.cpu(), x.sum(dim=1))
