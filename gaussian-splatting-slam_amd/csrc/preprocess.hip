@@ -109,6 +109,53 @@ __device__ __forceinline__ float sh_coef(const float* dc, const float* shs, int 
   return shs[((size_t)idx * stride + k) * 3 + c];
 }
 
+// ---- LDS staging of a block's SH rows (north_star: coalesced per-Gaussian attribute loads) -------------------------
+// The 256 rows of `shs` that a workgroup needs are one contiguous span of 256*S floats (S = 3*sh_stride; 48 KB at SH
+// degree 3).  Reading it as per-thread 12-B pieces at a 192-B stride costs 48 uncoalesced dword loads per lane; instead
+// the span is copied with flat 16-B/lane loads into LDS rows of ODD stride Sp = S|1 (a thread walking its own row then
+// hits 32 distinct banks across the wave), and the gradient rows go back to HBM the same way.
+__device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int nflt, int S, int Sp, float* lds) {
+  const int n4 = nflt >> 2;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    const int e = i * 4;
+    int r = e / S, c = e - r * S;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      lds[r * Sp + c] = vv[k];
+      if (++c == S) { c = 0; r++; }
+    }
+  }
+  for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {
+    const int r = e / S, c = e - r * S;
+    lds[r * Sp + c] = src[e];
+  }
+}
+__device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, int nflt, int S, int Sp, const float* lds) {
+  const int n4 = nflt >> 2;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const int e = i * 4;
+    int r = e / S, c = e - r * S;
+    float vv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      vv[k] = lds[r * Sp + c];
+      if (++c == S) { c = 0; r++; }
+    }
+    reinterpret_cast<float4*>(dst)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  }
+  for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {
+    const int r = e / S, c = e - r * S;
+    dst[e] = lds[r * Sp + c];
+  }
+}
+// coefficient k of channel c of this thread's Gaussian, staged variant
+__device__ __forceinline__ float sh_coef_lds(const float* dc, const float* row, int idx, int k, int c) {
+  if (dc) return (k == 0) ? dc[3 * (size_t)idx + c] : row[(k - 1) * 3 + c];
+  return row[k * 3 + c];
+}
+
 __device__ __forceinline__ void sh_basis_eval(int deg, float x, float y, float z, float* b /*16*/) {
   b[0] = SH_C0;
   if (deg > 0) {
@@ -138,6 +185,7 @@ __device__ __forceinline__ void sh_basis_eval(int deg, float x, float y, float z
 // ---------------------------------------------------------------------------------------------------
 // K1 forward
 // ---------------------------------------------------------------------------------------------------
+template <bool STAGE>
 __global__ __launch_bounds__(256) void k_preprocess_fwd(
     int P, int deg, int sh_stride, const float* __restrict__ means3D, const float* __restrict__ dc,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -147,8 +195,17 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
     uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) float sh_lds[];
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int S = 3 * sh_stride, Sp = S | 1;
+  if (STAGE) {
+    const size_t row0 = (size_t)blockIdx.x * 256;
+    const int rows = (int)min((size_t)256, (size_t)P - row0);
+    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds);
+    __syncthreads();
+  }
   if (idx >= P) return;
+  const float* my_row = sh_lds + threadIdx.x * Sp;
   PreView v;
   load_view(viewmatrix, projmatrix, campos, v);
 
@@ -220,7 +277,8 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
           rgb[0] = rgb[1] = rgb[2] = 0.f;
           for (int k = 0; k < K; k++) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) rgb[ch] += bs[k] * sh_coef(dc, shs, sh_stride, idx, k, ch);
+            for (int ch = 0; ch < 3; ch++)
+              rgb[ch] += bs[k] * (STAGE ? sh_coef_lds(dc, my_row, idx, k, ch) : sh_coef(dc, shs, sh_stride, idx, k, ch));
           }
 #pragma unroll
           for (int ch = 0; ch < 3; ch++) {
@@ -257,6 +315,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
 // igrad record (render backward): (d_mx_ndc, d_my_ndc, dA, dB) (dC, d_opacity_eff, d_r, d_g) (d_b, d_invdepth, -, -)
 // where dB is the true derivative wrt conic.B (power = -0.5(A dx^2 + C dy^2) - B dx dy).
 // ---------------------------------------------------------------------------------------------------
+template <bool STAGE>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int P, int deg, int sh_stride, const float* __restrict__ means3D, const float* __restrict__ dc,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -268,8 +327,17 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float* __restrict__ dL_ddc, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dcov3D) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= P) return;
+  extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+  const int S = 3 * sh_stride, Sp = S | 1;
+  const size_t row0 = (size_t)blockIdx.x * 256;
+  const int rows = (int)min((size_t)256, (size_t)P - row0);
+  if (STAGE) {
+    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds);
+    __syncthreads();
+  }
+  float* my_row = sh_lds + threadIdx.x * Sp;
+  const bool active = blockIdx.x * 256 + threadIdx.x < P;
+  const int idx = active ? blockIdx.x * 256 + threadIdx.x : P - 1;   // idle tail threads mirror the last Gaussian (no stores)
   const int K = (deg + 1) * (deg + 1);
   const bool visible = radii[idx] > 0;
 
@@ -341,8 +409,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       if (deg > 0) {
         float q[16];
         for (int k = 1; k < K; k++) {
-          q[k] = sh_coef(dc, shs, sh_stride, idx, k, 0) * g_rgb[0] + sh_coef(dc, shs, sh_stride, idx, k, 1) * g_rgb[1] +
-                 sh_coef(dc, shs, sh_stride, idx, k, 2) * g_rgb[2];
+          q[k] = STAGE ? (sh_coef_lds(dc, my_row, idx, k, 0) * g_rgb[0] + sh_coef_lds(dc, my_row, idx, k, 1) * g_rgb[1] +
+                          sh_coef_lds(dc, my_row, idx, k, 2) * g_rgb[2])
+                       : (sh_coef(dc, shs, sh_stride, idx, k, 0) * g_rgb[0] + sh_coef(dc, shs, sh_stride, idx, k, 1) * g_rgb[1] +
+                          sh_coef(dc, shs, sh_stride, idx, k, 2) * g_rgb[2]);
         }
         gdx += -SH_C1 * q[3];
         gdy += -SH_C1 * q[1];
@@ -497,38 +567,58 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   }
 
   // ---- write every output (zeros for culled Gaussians: no memset pass needed) ----
+  if (active) {
 #pragma unroll
-  for (int j = 0; j < 3; j++) dL_dmeans3D[3 * (size_t)idx + j] = g_mean[j];
-  dL_dmeans2D[3 * (size_t)idx + 0] = g_m2d[0];
-  dL_dmeans2D[3 * (size_t)idx + 1] = g_m2d[1];
-  dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
-  dL_dopacities[idx] = g_opac;
-  if (dL_dcolors) {
+    for (int j = 0; j < 3; j++) dL_dmeans3D[3 * (size_t)idx + j] = g_mean[j];
+    dL_dmeans2D[3 * (size_t)idx + 0] = g_m2d[0];
+    dL_dmeans2D[3 * (size_t)idx + 1] = g_m2d[1];
+    dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
+    dL_dopacities[idx] = g_opac;
+    if (dL_dcolors) {
 #pragma unroll
-    for (int j = 0; j < 3; j++) dL_dcolors[3 * (size_t)idx + j] = g_col[j];
-  }
-  if (dL_dcov3D) {
+      for (int j = 0; j < 3; j++) dL_dcolors[3 * (size_t)idx + j] = g_col[j];
+    }
+    if (dL_dcov3D) {
 #pragma unroll
-    for (int j = 0; j < 6; j++) dL_dcov3D[6 * (size_t)idx + j] = g_cov6[j];
-  }
-  if (dL_dscales) {
+      for (int j = 0; j < 6; j++) dL_dcov3D[6 * (size_t)idx + j] = g_cov6[j];
+    }
+    if (dL_dscales) {
 #pragma unroll
-    for (int j = 0; j < 3; j++) dL_dscales[3 * (size_t)idx + j] = g_scale[j];
-  }
-  if (dL_drotations) {
+      for (int j = 0; j < 3; j++) dL_dscales[3 * (size_t)idx + j] = g_scale[j];
+    }
+    if (dL_drotations) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) dL_drotations[4 * (size_t)idx + j] = g_rot[j];
+      for (int j = 0; j < 4; j++) dL_drotations[4 * (size_t)idx + j] = g_rot[j];
+    }
   }
   if (dL_dshs || dL_ddc) {
     // stored coefficients beyond the active degree get zero gradient
     const int stored = sh_stride + (dL_ddc ? 1 : 0);
-    for (int k = 0; k < stored; k++) {
-      const float bk = (have_sh && k < K) ? bs[k] : 0.f;
-      float* dst = dL_ddc ? ((k == 0) ? dL_ddc + 3 * (size_t)idx : dL_dshs + ((size_t)idx * sh_stride + (k - 1)) * 3)
-                          : dL_dshs + ((size_t)idx * sh_stride + k) * 3;
-      dst[0] = bk * g_col[0];
-      dst[1] = bk * g_col[1];
-      dst[2] = bk * g_col[2];
+    if (STAGE) {
+      // the thread has consumed its own SH row: overwrite it with the gradient row, then one flat coalesced copy-out
+      for (int k = 0; k < stored; k++) {
+        const float bk = (have_sh && k < K) ? bs[k] : 0.f;
+        if (dL_ddc && k == 0) {
+          if (active) {
+            float* d0 = dL_ddc + 3 * (size_t)idx;
+            d0[0] = bk * g_col[0]; d0[1] = bk * g_col[1]; d0[2] = bk * g_col[2];
+          }
+        } else {
+          float* dst = my_row + (dL_ddc ? (k - 1) : k) * 3;
+          dst[0] = bk * g_col[0]; dst[1] = bk * g_col[1]; dst[2] = bk * g_col[2];
+        }
+      }
+      __syncthreads();
+      stage_rows_out(dL_dshs + row0 * S, rows * S, S, Sp, sh_lds);
+    } else if (active) {
+      for (int k = 0; k < stored; k++) {
+        const float bk = (have_sh && k < K) ? bs[k] : 0.f;
+        float* dst = dL_ddc ? ((k == 0) ? dL_ddc + 3 * (size_t)idx : dL_dshs + ((size_t)idx * sh_stride + (k - 1)) * 3)
+                            : dL_dshs + ((size_t)idx * sh_stride + k) * 3;
+        dst[0] = bk * g_col[0];
+        dst[1] = bk * g_col[1];
+        dst[2] = bk * g_col[2];
+      }
     }
   }
 }
@@ -545,29 +635,55 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 // ---------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------
+// LDS staging applies when the rasterizer reads every stored coefficient of `shs` (active degree == stored degree),
+// the span is 16-B aligned and 256 padded rows fit comfortably (<= 64 KB so that two workgroups share a CU).
+static bool can_stage_sh(const gsr_settings* s, const gsr_gaussians* g, size_t* lds_bytes) {
+  if (!g->shs || g->colors_precomp || g->sh_coeffs <= 0) return false;
+  const int K = (s->sh_degree + 1) * (s->sh_degree + 1);
+  if (K - (g->dc ? 1 : 0) != g->sh_coeffs) return false;
+  if (((uintptr_t)g->shs & 15) != 0) return false;
+  const size_t bytes = (size_t)256 * ((3 * g->sh_coeffs) | 1) * sizeof(float);
+  if (bytes > 64 * 1024) return false;
+  *lds_bytes = bytes;
+  return true;
+}
+
 void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, int32_t* radii, char* geom,
                                const GsrGeomLayout& L, hipStream_t st) {
   const int P = g->P;
-  GSR_LAUNCH("preprocess_fwd", k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, st, P, s->sh_degree,
-             g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations,
-             g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width,
-             s->image_height, s->tanfovx, s->tanfovy, s->prefiltered, s->antialiasing, radii,
-             (float4*)(geom + L.rec), (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order),
-             (uint32_t*)(geom + L.tiles_touched), (ushort4*)(geom + L.rect), (uint8_t*)(geom + L.clamped),
-             (uint32_t*)(geom + L.meta));
+  size_t lds = 0;
+  const bool stage = can_stage_sh(s, g, &lds);
+#define GSR_PRE_FWD_ARGS                                                                                              \
+  P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations, \
+      g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width, s->image_height,  \
+      s->tanfovx, s->tanfovy, s->prefiltered, s->antialiasing, radii, (float4*)(geom + L.rec),                        \
+      (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles_touched),              \
+      (ushort4*)(geom + L.rect), (uint8_t*)(geom + L.clamped), (uint32_t*)(geom + L.meta)
+  if (stage)
+    GSR_LAUNCH("preprocess_fwd", k_preprocess_fwd<true>, dim3((P + 255) / 256), dim3(256), lds, st, GSR_PRE_FWD_ARGS);
+  else
+    GSR_LAUNCH("preprocess_fwd", k_preprocess_fwd<false>, dim3((P + 255) / 256), dim3(256), 0, st, GSR_PRE_FWD_ARGS);
+#undef GSR_PRE_FWD_ARGS
 }
 
 void gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii,
                                const char* geom, const GsrGeomLayout& L, const float4* igrad, const gsr_grads* gr,
                                hipStream_t st) {
   const int P = g->P;
-  GSR_LAUNCH("preprocess_bwd", k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, st, P, s->sh_degree,
-             g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations,
-             g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width,
-             s->image_height, s->tanfovx, s->tanfovy, s->antialiasing, radii, (const uint8_t*)(geom + L.clamped),
-             (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), igrad,
-             gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities,
-             gr->dL_dscales, gr->dL_drotations, gr->dL_dcov3D);
+  size_t lds = 0;
+  const bool stage = can_stage_sh(s, g, &lds) && gr->dL_dshs && (((uintptr_t)gr->dL_dshs & 15) == 0);
+#define GSR_PRE_BWD_ARGS                                                                                              \
+  P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations, \
+      g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width, s->image_height,  \
+      s->tanfovx, s->tanfovy, s->antialiasing, radii, (const uint8_t*)(geom + L.clamped),                             \
+      (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), igrad, gr->dL_dmeans3D,      \
+      gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities, gr->dL_dscales, gr->dL_drotations, \
+      gr->dL_dcov3D
+  if (stage)
+    GSR_LAUNCH("preprocess_bwd", k_preprocess_bwd<true>, dim3((P + 255) / 256), dim3(256), lds, st, GSR_PRE_BWD_ARGS);
+  else
+    GSR_LAUNCH("preprocess_bwd", k_preprocess_bwd<false>, dim3((P + 255) / 256), dim3(256), 0, st, GSR_PRE_BWD_ARGS);
+#undef GSR_PRE_BWD_ARGS
 }
 
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
