@@ -62,15 +62,18 @@ def build_scene(args, device, rank, world):
     teacher = GaussianModel.from_raw(teacher_raw.to(device), requires_grad=False)
     my_views = list(range(len(cams)))[rank::world]
     log(f"scene generated: P={cfg['P']} views={len(cams)}; rendering {len(my_views)} teacher views")
-    gts = {}
+    gts, depth_gts = {}, ({} if cfg.get("depth_grad") else None)
     with torch.no_grad():
         for v in my_views:
-            gts[v] = render(cams[v], teacher, pipe, bg)["render"].clamp(0, 1).clone()
+            pkg = render(cams[v], teacher, pipe, bg)
+            gts[v] = pkg["render"].clamp(0, 1).clone()
+            if depth_gts is not None:
+                depth_gts[v] = pkg["depth"].clone()
     del teacher
     torch.cuda.synchronize()
     log("teacher views rendered")
     model = GaussianModel.from_raw(raw.to(device), requires_grad=True)
-    return model, cams, gts, my_views, pipe, bg, cfg, render
+    return model, cams, gts, depth_gts, my_views, pipe, bg, cfg, render
 
 
 def kernel_table(prof, R, N, P, M):
@@ -186,9 +189,10 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
-    model, cams, gts, my_views, pipe, bg, cfg, render = build_scene(args, device, rank, world)
+    model, cams, gts, depth_gts, my_views, pipe, bg, cfg, render = build_scene(args, device, rank, world)
     trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=args.optimizer,
-                      loss=args.loss, separate_sh=not args.concat_sh)
+                      loss=args.loss, separate_sh=not args.concat_sh, depth_targets=depth_gts,
+                      depth_weight=1.0 if depth_gts is not None else 0.0)
     P = cfg["P"]
     M = (cfg["deg"] + 1) ** 2
     W, H = cfg["W"], cfg["H"]

@@ -1,6 +1,7 @@
 // api.hip - extern "C" entry points of libgsr_hip.so (declared in include/gsr.h) and host orchestration.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -43,6 +44,14 @@ int gsr_check(hipError_t e, const char* what) {
 }
 
 static int debug_sync(const gsr_settings* s, hipStream_t st, const char* stage) {
+  static const bool trace = getenv("GSR_TRACE") != nullptr;   // GSR_TRACE=1: name every stage on stderr as it completes
+  if (trace) {
+    fprintf(stderr, "[gsr] launched: %s\n", stage);
+    fflush(stderr);
+    hipError_t e = hipStreamSynchronize(st);
+    fprintf(stderr, "[gsr] done    : %s (%s)\n", stage, hipGetErrorString(e));
+    fflush(stderr);
+  }
   if (!s->debug) return 0;
   hipError_t e = hipStreamSynchronize(st);
   if (e == hipSuccess) e = hipGetLastError();

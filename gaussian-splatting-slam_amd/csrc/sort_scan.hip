@@ -184,63 +184,92 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ ta
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// Scatter pass.  Each workgroup owns one chunk of 4096 keys (16 per thread, element s*256+tid so that the original
+// order is (sub-tile, wave, lane)).  Phase 1 ranks every key inside its (chunk, digit) group with wave ballots (stable);
+// phase 2 sorts the chunk locally into LDS; phase 3 streams LDS out so that each digit's run lands in consecutive global
+// addresses (64-B+ runs instead of the 4-B scattered stores of a direct scatter).
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                        const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        const uint32_t* __restrict__ table_excl,
                                                        const uint32_t* __restrict__ totals, size_t n, int shift,
                                                        uint32_t mask, uint32_t nblk) {
-  __shared__ uint32_t digit_base[GSR_RADIX_SIZE];
+  __shared__ uint32_t digit_run[GSR_RADIX_SIZE];    // keys of each digit seen so far in this chunk -> final: local count
   __shared__ uint32_t wave_cnt[4][GSR_RADIX_SIZE];
+  __shared__ uint32_t lstart[GSR_RADIX_SIZE];       // first local (sorted) position of each digit
+  __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
+  __shared__ uint32_t lkeys[GSR_RADIX_CHUNK];
+  __shared__ uint32_t lvals[GSR_RADIX_CHUNK];
   __shared__ uint32_t lds4[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   {
     uint32_t tot;
-    const uint32_t digit_start = block_excl_scan_u32(totals[tid], &tot, lds4);   // keys with a smaller digit
-    digit_base[tid] = digit_start + table_excl[(size_t)tid * nblk + blockIdx.x];
+    const uint32_t digit_start = block_excl_scan_u32(totals[tid], &tot, lds4);   // keys with a smaller digit, whole array
+    gbase[tid] = digit_start + table_excl[(size_t)tid * nblk + blockIdx.x];
   }
+  digit_run[tid] = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) wave_cnt[i][tid] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * GSR_RADIX_CHUNK;
+  const uint32_t count = (uint32_t)min((size_t)GSR_RADIX_CHUNK, n - base);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int s = 0; s < GSR_RADIX_SUBTILES; s++) {
-    const size_t k = base + (size_t)s * 256 + tid;
-    if (base + (size_t)s * 256 >= n) break;  // block-uniform
-    const bool active = k < n;
-    uint32_t key = 0, val = 0, d = 0;
-    if (active) {
-      key = keys_in[k];
-      val = vals_in ? vals_in[k] : (uint32_t)k;
-      d = (key >> shift) & mask;
-    }
-    // lanes of this wave holding the same digit
-    unsigned long long peers = __ballot(active);
+  uint32_t key[GSR_RADIX_SUBTILES], val[GSR_RADIX_SUBTILES], rk[GSR_RADIX_SUBTILES];   // rk = digit << 16 | local rank
 #pragma unroll
-    for (int b = 0; b < GSR_RADIX_BITS; b++) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long bal = __ballot(active && bit);
-      peers &= bit ? bal : ~bal;
-    }
-    const uint32_t rank = __popcll(peers & lt_mask);
-    if (active && rank == 0) wave_cnt[w][d] = __popcll(peers);
-    __syncthreads();
+  for (int s = 0; s < GSR_RADIX_SUBTILES; s++) {
+    const uint32_t li = (uint32_t)s * 256 + tid;
+    const bool active = li < count;
+    uint32_t d = 0;
+    key[s] = 0; val[s] = 0;
     if (active) {
-      uint32_t off = digit_base[d] + rank;
+      key[s] = keys_in[base + li];
+      val[s] = vals_in ? vals_in[base + li] : (uint32_t)(base + li);
+      d = (key[s] >> shift) & mask;
+    }
+    if ((uint32_t)s * 256 < count) {   // block-uniform
+      unsigned long long peers = __ballot(active);
+#pragma unroll
+      for (int b = 0; b < GSR_RADIX_BITS; b++) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(active && bit);
+        peers &= bit ? bal : ~bal;
+      }
+      const uint32_t rank = __popcll(peers & lt_mask);
+      if (active && rank == 0) wave_cnt[w][d] = __popcll(peers);
+      __syncthreads();
+      uint32_t off = digit_run[d] + rank;
 #pragma unroll
       for (int i = 0; i < 3; i++)
         if (i < w) off += wave_cnt[i][d];
-      keys_out[off] = key;
-      vals_out[off] = val;
-    }
-    __syncthreads();
-    {
-      uint32_t add = wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
-      digit_base[tid] += add;
+      rk[s] = (d << 16) | off;
+      __syncthreads();
+      digit_run[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
 #pragma unroll
       for (int i = 0; i < 4; i++) wave_cnt[i][tid] = 0;
+      __syncthreads();
     }
-    __syncthreads();
+  }
+  {
+    uint32_t tot;
+    lstart[tid] = block_excl_scan_u32(digit_run[tid], &tot, lds4);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < GSR_RADIX_SUBTILES; s++) {
+    const uint32_t li = (uint32_t)s * 256 + tid;
+    if (li < count) {
+      const uint32_t lp = lstart[rk[s] >> 16] + (rk[s] & 0xFFFFu);
+      lkeys[lp] = key[s];
+      lvals[lp] = val[s];
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < count; i += 256) {
+    const uint32_t k = lkeys[i];
+    const uint32_t d = (k >> shift) & mask;
+    const uint32_t g = gbase[d] + (i - lstart[d]);
+    keys_out[g] = k;
+    vals_out[g] = lvals[i];
   }
 }
 
