@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--concat-sh", action="store_true",
                     help="pass torch.cat(dc, rest) as shs (separate_sh=False); default mirrors reference train.py:106 with "
                          "SparseGaussianAdam importable: separate_sh=True")
+    ap.add_argument("--densify", action="store_true",
+                    help="run the reference densify/prune schedule (train.py:155-168) inside the timed loop (config 5)")
+    ap.add_argument("--densify-from", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
@@ -193,6 +196,9 @@ def main():
     trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=args.optimizer,
                       loss=args.loss, separate_sh=not args.concat_sh, depth_targets=depth_gts,
                       depth_weight=1.0 if depth_gts is not None else 0.0)
+    if args.densify:
+        # cameras_extent of the reference = 1.1 x radius of the camera centres (scene/dataset_readers.py getNerfppNorm)
+        trainer.enable_densification(extent=1.1 * 4.0, from_iter=args.densify_from)
     P = cfg["P"]
     M = (cfg["deg"] + 1) ** 2
     W, H = cfg["W"], cfg["H"]
@@ -220,7 +226,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step; Gaussians now {model.get_xyz.shape[0]}")
     result = {
         "metric": "train_iters_per_sec", "value": round(world * args.steps / elapsed, 3),
         "unit": "view-iterations/s (render fwd + L1/DSSIM loss + bwd + Adam)", "n_gpus": world,
@@ -229,7 +235,8 @@ def main():
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {P} Gaussians, SH degree {cfg['deg']}, "
                                f"{W}x{H}, {len(cams)} views, one view per rank per step, all-reduce of "
                                f"{59 if cfg['deg'] == 3 else 11 + 3 * M}-float/Gaussian grads when N>1",
-                   "gaussians": P, "sh_degree": cfg["deg"], "width": W, "height": H, "views": len(cams),
+                   "gaussians": P, "gaussians_final": int(model.get_xyz.shape[0]), "densify": bool(args.densify),
+                   "sh_degree": cfg["deg"], "width": W, "height": H, "views": len(cams),
                    "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}",
                    "loss": "L1 + 0.2 DSSIM (" + ("HIP fused SSIM" if args.loss == "hip" else "torch conv2d SSIM") + ")",
                    "optimizer": {"hip": "Adam, one-launch HIP kernel (torch.optim.Adam semantics)",
@@ -266,7 +273,7 @@ def main():
         prof = _C.profile_read()
         lib.gsr_profile_enable(0)
         R = sum(Rs) / len(Rs)
-        kt = kernel_table(prof, R, W * H, P, M)
+        kt = kernel_table(prof, R, W * H, int(model.get_xyz.shape[0]), M)
         result["num_rendered_avg"] = int(R)
         result["kernels"] = kt
         named = {k: v for k, v in kt.items() if "alg_bytes" in v}

@@ -101,3 +101,137 @@ class GaussianModel:
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training-time state and densification (reference scene/gaussian_model.py:155-191 training_setup, :226-229 reset_opacity,
+# :274-433 optimizer surgery / densify / prune / statistics).  The decisions and the row gather run in HIP
+# (csrc/densify.hip) behind the C ABI; there is no PyTorch fallback.
+# ---------------------------------------------------------------------------------------------------------------------
+def _inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+_PARAM_ATTRS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+_GROUP_NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+
+def training_setup(self, optimizer="hip", percent_dense=0.01, **lrs):
+    """optimizer: "hip" (FusedAdam), "hip_sparse" (SparseGaussianAdam) or "torch" (torch.optim.Adam, CPU tests)."""
+    self.percent_dense = percent_dense
+    dev = self._xyz.device
+    P = self._xyz.shape[0]
+    self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
+    self.denom = torch.zeros((P, 1), device=dev)
+    self.max_radii2D = torch.zeros((P,), device=dev)
+    groups = self.param_groups(**lrs)
+    if optimizer == "torch":
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+    elif optimizer == "hip":
+        from diff_gaussian_rasterization import FusedAdam
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+    elif optimizer == "hip_sparse":
+        from diff_gaussian_rasterization import SparseGaussianAdam
+        self.optimizer = SparseGaussianAdam(groups, lr=0.0, eps=1e-15)
+    else:
+        raise ValueError(optimizer)
+    self.optimizer_kind = optimizer
+    return self.optimizer
+
+
+def add_densification_stats(self, viewspace_point_tensor, update_filter, radii=None):
+    """reference gaussian_model.py:431-433 (+ train.py:159 max_radii2D), written without boolean-mask indexing (no
+    device->host sync): the gradient and the radii are zero where update_filter is False."""
+    with torch.no_grad():
+        if radii is not None:
+            torch.maximum(self.max_radii2D, radii.float(), out=self.max_radii2D)
+        self.xyz_gradient_accum += torch.norm(viewspace_point_tensor.grad[:, :2], dim=-1, keepdim=True) * update_filter[:, None]
+        self.denom += update_filter[:, None]
+
+
+def _replace_params(self, new_tensors, new_moments=None):
+    """Swap the six parameters (and their Adam moments) in the model and in the optimizer's groups / state."""
+    new_params = []
+    for gi, (attr, t) in enumerate(zip(_PARAM_ATTRS, new_tensors)):
+        old = getattr(self, attr)
+        p = nn.Parameter(t.requires_grad_(True))
+        setattr(self, attr, p)
+        new_params.append(p)
+        opt = getattr(self, "optimizer", None)
+        if opt is None:
+            continue
+        for group in opt.param_groups:
+            if group["name"] == _GROUP_NAMES[gi]:
+                st = opt.state.pop(old, None)
+                group["params"][0] = p
+                if st is not None:
+                    if new_moments is not None and new_moments[gi] is not None:
+                        st["exp_avg"], st["exp_avg_sq"] = new_moments[gi]
+                    opt.state[p] = st
+    return new_params
+
+
+def reset_opacity(self):
+    """reference gaussian_model.py:226-229: opacity <- min(opacity, 0.01), moments of the opacity group zeroed."""
+    with torch.no_grad():
+        new = _inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
+        old = self._opacity
+        p = nn.Parameter(new.requires_grad_(True))
+        self._opacity = p
+        for group in self.optimizer.param_groups:
+            if group["name"] == "opacity":
+                st = self.optimizer.state.pop(old, None)
+                group["params"][0] = p
+                if st is not None:
+                    st["exp_avg"] = torch.zeros_like(new)
+                    st["exp_avg_sq"] = torch.zeros_like(new)
+                    self.optimizer.state[p] = st
+
+
+def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, radii=None, seed=0, return_source=False):
+    """reference gaussian_model.py:412-429.  Returns (n_keep, n_clone, n_split_sources[, source row of every new row])."""
+    import ctypes as C
+    from diff_gaussian_rasterization import _C
+    lib = _C.lib()
+    if not self._xyz.is_cuda:
+        raise _C.GsrError("densify_and_prune runs in HIP kernels (no CPU path)")
+    dev = self._xyz.device
+    P = int(self._xyz.shape[0])
+    with torch.no_grad(), torch.cuda.device(dev):
+        params = [getattr(self, a).data.contiguous() for a in _PARAM_ATTRS]
+        rows = [int(p.numel() // max(P, 1)) for p in params]
+        moments = []
+        for a in _PARAM_ATTRS:
+            st = self.optimizer.state.get(getattr(self, a), None) if getattr(self, "optimizer", None) is not None else None
+            moments.append((st["exp_avg"].contiguous(), st["exp_avg_sq"].contiguous()) if st and "exp_avg" in st else None)
+        ws = torch.empty(lib.gsr_densify_workspace_bytes(P), dtype=torch.uint8, device=dev)
+        counts = (C.c_int64 * 3)()
+        _C.check(lib.gsr_densify_plan(P, _C.ptr(self.xyz_gradient_accum.contiguous()), _C.ptr(self.denom.contiguous()),
+                                      _C.ptr(params[4]), _C.ptr(params[3]), float(max_grad), float(min_opacity),
+                                      float(extent), float(self.percent_dense), 1 if max_screen_size else 0, _C.ptr(ws),
+                                      ws.numel(), counts, _C._stream()))
+        nk, nc, ns = int(counts[0]), int(counts[1]), int(counts[2])
+        newP = nk + nc + 2 * ns
+        outs = [torch.empty((newP,) + tuple(p.shape[1:]), dtype=torch.float32, device=dev) for p in params]
+        out_m = [None if m is None else (torch.empty_like(o), torch.empty_like(o)) for m, o in zip(moments, outs)]
+        ins18, outs18 = [], []
+        for p, m, o, om in zip(params, moments, outs, out_m):
+            ins18 += [p.data_ptr(), m[0].data_ptr() if m else None, m[1].data_ptr() if m else None]
+            outs18 += [o.data_ptr(), om[0].data_ptr() if om else None, om[1].data_ptr() if om else None]
+        vin = (C.c_void_p * 18)(*ins18)
+        vout = (C.c_void_p * 18)(*outs18)
+        rowf = (C.c_int32 * 6)(*rows)
+        src = torch.empty(newP, dtype=torch.int32, device=dev) if return_source else None
+        _C.check(lib.gsr_densify_apply(P, _C.ptr(ws), vin, vout, rowf, nk, nc, ns, int(seed) & 0xFFFFFFFF, _C.ptr(src),
+                                       _C._stream()))
+        _replace_params(self, outs, out_m)
+        self.xyz_gradient_accum = torch.zeros((newP, 1), device=dev)      # densification_postfix :362-364
+        self.denom = torch.zeros((newP, 1), device=dev)
+        self.max_radii2D = torch.zeros((newP,), device=dev)
+    return (nk, nc, ns, src) if return_source else (nk, nc, ns)
+
+
+GaussianModel.training_setup = training_setup
+GaussianModel.add_densification_stats = add_densification_stats
+GaussianModel.reset_opacity = reset_opacity
+GaussianModel.densify_and_prune = densify_and_prune

@@ -1,12 +1,12 @@
 """Training-step harness with the shape of the reference loop (train.py:96-137 forward+loss+backward,
-:159-160 densification statistics, :170-179 optimizer step), used by bench.py and the tests.  It is a CALLER of the
-hot path (render()); the renderer is injected so CPU tests can drive the same logic with the oracle."""
+:155-168 densification statistics / densify / opacity reset, :170-179 optimizer step), used by bench.py and the tests.  It
+is a CALLER of the hot path (render()); the renderer is injected so CPU tests can drive the same logic with the oracle."""
 from __future__ import annotations
 
 import torch
 
 from .losses import training_loss, training_loss_fused
-from .parallel import GradBucket
+from .parallel import GradBucket, reduce_densification_stats
 
 
 class Trainer:
@@ -19,28 +19,36 @@ class Trainer:
         self.render_fn, self.pipe, self.bg = render_fn, pipe, bg
         self.lambda_dssim = lambda_dssim
         self.world, self.rank = world, rank
-        dev = model.get_xyz.device
         self.optimizer_kind = optimizer
-        if optimizer == "torch":
-            self.optimizer = torch.optim.Adam(model.param_groups(), lr=0.0, eps=1e-15)   # scene/gaussian_model.py:170
-        elif optimizer == "hip":
-            from diff_gaussian_rasterization import FusedAdam
-            self.optimizer = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15)
-        elif optimizer == "hip_sparse":
-            from diff_gaussian_rasterization import SparseGaussianAdam
-            self.optimizer = SparseGaussianAdam(model.param_groups(), lr=0.0, eps=1e-15)  # scene/gaussian_model.py:173
-        else:
-            raise ValueError(optimizer)
+        # like the reference, the model owns the optimizer and the densification statistics (gaussian_model.py:155-176)
+        self.optimizer = model.training_setup(optimizer=optimizer)
         self.loss_fn = {"hip": training_loss_fused, "torch": training_loss}[loss]
         self.bucket = GradBucket(model.parameters()) if world > 1 else None
-        P = model.get_xyz.shape[0]
-        self.xyz_gradient_accum = torch.zeros(P, 1, device=dev)
-        self.denom = torch.zeros(P, 1, device=dev)
-        self.max_radii2D = torch.zeros(P, device=dev)
         self.depth_targets, self.depth_weight = depth_targets, depth_weight
         # reference train.py:106 passes separate_sh=SPARSE_ADAM_AVAILABLE: dc / rest go to the rasterizer unconcatenated
         self.separate_sh = separate_sh
+        self.densify = None          # schedule dict once enable_densification() is called
+        self.iteration = 0
         self.last = {}
+
+    # statistics live in the model (reference: GaussianModel.xyz_gradient_accum / denom / max_radii2D)
+    @property
+    def xyz_gradient_accum(self):
+        return self.model.xyz_gradient_accum
+
+    @property
+    def denom(self):
+        return self.model.denom
+
+    @property
+    def max_radii2D(self):
+        return self.model.max_radii2D
+
+    def enable_densification(self, extent, from_iter=500, until_iter=15000, interval=100, opacity_reset_interval=3000,
+                             grad_threshold=0.0002, min_opacity=0.005, seed=0):
+        """Schedule and thresholds of reference train.py:155-168 / arguments/__init__.py:84-90."""
+        self.densify = dict(extent=extent, from_iter=from_iter, until_iter=until_iter, interval=interval,
+                            reset=opacity_reset_interval, thr=grad_threshold, min_opacity=min_opacity, seed=seed)
 
     def step(self, view_idx: int):
         cam = self.cameras[view_idx]
@@ -50,19 +58,38 @@ class Trainer:
         if self.depth_weight > 0 and self.depth_targets is not None:
             loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[view_idx]).mean()
         loss.backward()
+        self.iteration += 1
+        self.last = dict(loss=loss.detach(), image=image.detach(), radii=radii)
         with torch.no_grad():
             # densification statistics are per-view: norm BEFORE any cross-rank reduction
-            # same values as reference train.py:159-160 / gaussian_model.py:431-433, written without boolean-mask
-            # indexing (which costs a device->host sync per step): radii and the gradient are 0 where not visible
-            torch.maximum(self.max_radii2D, radii.float(), out=self.max_radii2D)
-            self.xyz_gradient_accum += torch.norm(vsp.grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
-            self.denom += vis[:, None]
+            self.model.add_densification_stats(vsp, vis, radii)                              # train.py:159-160
             if self.bucket is not None:
                 self.bucket.all_reduce_mean(self.world)
+            if self.densify is not None:
+                # the reference densifies between backward and the optimizer step (train.py:155-168 before :170): the
+                # replaced Parameters carry no gradient, so the step that follows skips them, exactly like there
+                self._maybe_densify(radii)
             if self.optimizer_kind == "hip_sparse":
-                self.optimizer.step(vis, radii.shape[0])                               # train.py:173-175
+                self.optimizer.step(vis, radii.shape[0])                                       # train.py:173-175
             else:
                 self.optimizer.step()
             self.optimizer.zero_grad(set_to_none=True)
-        self.last = dict(loss=loss.detach(), image=image.detach(), radii=radii)
         return self.last
+
+    def _maybe_densify(self, radii):
+        d, it = self.densify, self.iteration
+        if it >= d["until_iter"]:
+            return
+        changed = False
+        if it > d["from_iter"] and it % d["interval"] == 0:
+            # per-view statistics -> identical on all ranks, so every rank takes the same decisions
+            reduce_densification_stats(self.model.xyz_gradient_accum, self.model.denom, self.model.max_radii2D, self.world)
+            size_threshold = 20 if it > d["reset"] else None
+            self.last["densify"] = self.model.densify_and_prune(d["thr"], d["min_opacity"], d["extent"], size_threshold,
+                                                                 radii, seed=d["seed"] + it)
+            changed = True
+        if it % d["reset"] == 0:
+            self.model.reset_opacity()
+            changed = True
+        if changed and self.bucket is not None:     # the replaced Parameters are new objects (and carry no gradient yet)
+            self.bucket = GradBucket(self.model.parameters())

@@ -157,6 +157,22 @@ int gsr_sparse_adam_step(int32_t count, float* const* params, const float* const
                          float* const* exp_avg_sq, const int64_t* numel, const float* lr, int64_t N,
                          const uint8_t* visible, double beta1, double beta2, double eps, void* stream);
 
+/* GaussianModel.densify_and_prune (reference scene/gaussian_model.py:367-429 + optimizer surgery :274-344) as two passes.
+ * plan: decides keep / clone / split per Gaussian with the reference's predicates (NaN grads -> 0; clone: small & grad >= thr;
+ * split: large & grad >= thr; prune: sigmoid(opacity) < min_opacity, or world size > 0.1*extent when use_world_size_prune),
+ * runs the prefix sums, and returns counts_host[3] = {kept originals, clones, split sources} (one stream sync).
+ * apply: writes the new arrays in the reference's order [kept originals][clones][children copy 0][children copy 1];
+ * in_ptrs / out_ptrs are HOST arrays of 18 device pointers: (xyz, f_dc, f_rest, opacity, scaling, rotation) x
+ * (value, exp_avg, exp_avg_sq); moments may be NULL.  New size = keep + clone + 2*child. */
+size_t gsr_densify_workspace_bytes(int64_t P);
+int gsr_densify_plan(int64_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling_raw,
+                     const float* opacity_raw, float max_grad, float min_opacity, float extent, float percent_dense,
+                     int32_t use_world_size_prune, void* workspace, size_t workspace_bytes, int64_t* counts_host,
+                     void* stream);
+int gsr_densify_apply(int64_t P, const void* workspace, const float* const* in_ptrs, float* const* out_ptrs,
+                      const int32_t* row_floats, int64_t n_keep, int64_t n_clone, int64_t n_child, uint32_t seed,
+                      int32_t* source_of_row, void* stream);
+
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline block). */
 void gsr_profile_enable(int32_t on);
 void gsr_profile_reset(void);

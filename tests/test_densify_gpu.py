@@ -1,0 +1,125 @@
+"""GPU parity of densify_and_prune: HIP plan/apply kernels against the CPU restatement of reference
+scene/gaussian_model.py:367-429 (oracle/densify_oracle.py).  Deterministic structure (which rows survive, are cloned, are split,
+their order, copied values, Adam moments) must match exactly; the split's normal samples are checked statistically."""
+import math
+
+import pytest
+import torch
+
+from oracle import densify_oracle as DO
+from scene_utils import make_gaussians, GaussianModel
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+ATTRS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+
+def _setup(P=6000, seed=3, with_moments=True):
+    raw = make_gaussians(P, 3, seed=seed, scale_factor=1.0)
+    gen = torch.Generator().manual_seed(seed + 1)
+    raw.scaling += 1.2 * torch.randn(P, 3, generator=gen)                 # wide spread around percent_dense * extent
+    raw.opacity[torch.rand(P, generator=gen) < 0.15] = -7.0              # some below min_opacity
+    model = GaussianModel.from_raw(raw.to("cuda"))
+    opt = model.training_setup(optimizer="hip")
+    if with_moments:
+        for p in model.parameters():
+            p.grad = torch.randn(p.shape, generator=gen).cuda() * 1e-3
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    accum = torch.rand(P, 1, generator=gen) * 0.002
+    den = torch.randint(0, 4, (P, 1), generator=gen).float()
+    accum[den == 0] = 0.0                                                 # 0/0 -> NaN -> 0 path
+    model.xyz_gradient_accum, model.denom = accum.cuda(), den.cuda()
+    model.max_radii2D = (torch.rand(P, generator=gen) * 50).cuda()
+    return model, opt, accum, den
+
+
+@pytest.mark.parametrize("max_screen_size", [None, 20])
+def test_densify_matches_reference_semantics(max_screen_size):
+    model, opt, accum, den = _setup()
+    P = accum.shape[0]
+    params = {n: getattr(model, a).detach().cpu().clone() for n, a in zip(NAMES, ATTRS)}
+    moments = {}
+    for n, a in zip(NAMES, ATTRS):
+        st = opt.state[getattr(model, a)]
+        moments[n] = (st["exp_avg"].cpu().clone(), st["exp_avg_sq"].cpu().clone())
+    extent, thr, min_op = 15.0, 0.0004, 0.005     # percent_dense*extent = 0.15 splits the scale distribution
+    ref_p, ref_m, info = DO.densify_and_prune(params, moments, accum.clone(), den.clone(), model.max_radii2D.cpu().clone(), thr,
+                                              min_op, extent, max_screen_size, model.percent_dense,
+                                              normal_samples=torch.zeros(0, 3) if False else None)
+    nk, nc, ns, src = model.densify_and_prune(thr, min_op, extent, max_screen_size, None, seed=11, return_source=True)
+    src = src.cpu().long()
+    kind = info["kind"]
+    assert (nk, nc, 2 * ns) == (int((kind == 0).sum()), int((kind == 1).sum()), int((kind == 2).sum()))
+    assert nk > 100 and nc > 100 and ns > 100                                  # the scene exercises every branch
+    assert torch.equal(src, info["source"])                                    # same rows, same order
+    newP = nk + nc + 2 * ns
+    assert model.get_xyz.shape[0] == newP and model.xyz_gradient_accum.shape == (newP, 1)
+    assert float(model.xyz_gradient_accum.abs().sum()) == 0 and float(model.max_radii2D.abs().sum()) == 0
+    det = kind != 2                                                            # kept + clones: everything exact
+    for n, a in zip(NAMES, ATTRS):
+        got = getattr(model, a).detach().cpu()
+        assert got.shape == ref_p[n].shape
+        assert torch.equal(got[det], ref_p[n][det]), n
+        st = opt.state[getattr(model, a)]
+        assert torch.equal(st["exp_avg"].cpu(), ref_m[n][0]) and torch.equal(st["exp_avg_sq"].cpu(), ref_m[n][1]), n
+        for g in opt.param_groups:
+            if g["name"] == n:
+                assert g["params"][0] is getattr(model, a)
+    ch = kind == 2
+    for n in ("f_dc", "f_rest", "opacity", "rotation"):
+        assert torch.equal(getattr(model, ATTRS[NAMES.index(n)]).detach().cpu()[ch], ref_p[n][ch]), n
+    assert torch.allclose(model._scaling.detach().cpu()[ch], ref_p["scaling"][ch], atol=2e-6)
+    # split samples: z = R^T (xyz_child - xyz_src) / exp(scaling_src)  ~  N(0,1)
+    s_idx = src[ch]
+    R = DO.build_rotation(params["rotation"][s_idx])
+    d = model._xyz.detach().cpu()[ch] - params["xyz"][s_idx]
+    z = torch.bmm(R.transpose(1, 2), d.unsqueeze(-1)).squeeze(-1) / torch.exp(params["scaling"][s_idx])
+    n = z.numel()
+    assert abs(float(z.mean())) < 5.0 / math.sqrt(n) and abs(float(z.std()) - 1.0) < 0.05
+    assert float((z.abs() > 4.5).float().mean()) < 1e-3
+    half = z.shape[0] // 2
+    assert not torch.allclose(z[:half], z[half:])                              # the two copies are independent draws
+    assert abs(float((z[:half] * z[half:]).mean())) < 0.05
+
+
+def test_densify_without_optimizer_state_and_reset_opacity():
+    model, opt, accum, den = _setup(P=1500, with_moments=False)
+    before = model.get_opacity.detach().clone()
+    nk, nc, ns = model.densify_and_prune(0.0004, 0.005, 2.0, None)
+    assert model.get_xyz.shape[0] == nk + nc + 2 * ns
+    model.reset_opacity()
+    assert float(model.get_opacity.max()) <= 0.01 + 1e-6
+    for g in opt.param_groups:
+        if g["name"] == "opacity":
+            assert g["params"][0] is model._opacity
+    # training continues on the new parameter set
+    for p in model.parameters():
+        p.grad = torch.ones_like(p) * 1e-3
+    opt.step()
+    assert torch.isfinite(model._xyz).all()
+
+
+def test_training_with_densification_schedule():
+    """Trainer end-to-end with the reference schedule compressed (densify every 5 its from it 5): the row count changes,
+    rendering / loss / Adam keep working, and the loss stays finite."""
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import fibonacci_cameras, Trainer
+    raw = make_gaussians(4000, 1, seed=8, scale_factor=0.8)
+    cams = fibonacci_cameras(3, 160, 96, seed=9, device="cuda")
+    teacher = GaussianModel.from_raw(make_gaussians(4000, 1, seed=10, scale_factor=0.8).to("cuda"), requires_grad=False)
+    bg = torch.zeros(3, device="cuda")
+    pipe = PipelineParams()
+    with torch.no_grad():
+        gts = {i: render(c, teacher, pipe, bg)["render"].clone() for i, c in enumerate(cams)}
+    model = GaussianModel.from_raw(raw.to("cuda"))
+    tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True)
+    tr.enable_densification(extent=2.0, from_iter=4, until_iter=40, interval=5, opacity_reset_interval=15, grad_threshold=1e-5)
+    sizes = []
+    for it in range(30):
+        out = tr.step(it % 3)
+        sizes.append(model.get_xyz.shape[0])
+        assert torch.isfinite(out["loss"])
+    assert len(set(sizes)) > 2
+    assert model.xyz_gradient_accum.shape[0] == sizes[-1]
