@@ -76,6 +76,20 @@ def build_scene(args, device, rank, world):
     return model, cams, gts, depth_gts, my_views, pipe, bg, cfg, render
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, made by
+    tools/pmc_summary.py: FETCH_SIZE x 1024 x 2 [gfx950 correction] + WRITE_SIZE x 1024, separate passes, C3 workload).
+    None when no counter data is committed for it."""
+    try:
+        data = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
+    except Exception:
+        return None
+    for name, v in data.items():
+        if name.split("<")[0] == "k_" + kernel:
+            return int(v["traffic_bytes"])
+    return None
+
+
 def kernel_table(prof, R, N, P, M):
     """Algorithmic HBM bytes per launch (SURVEY.md 8(d) per-unit figures x units per launch; DESIGN.md 'Kernels')."""
     b_in = 44 + 12 * M
@@ -281,7 +295,8 @@ def main():
             dom = max(named, key=lambda k: named[k]["avg_ms"])
             d = named[dom]
             result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": d["gbps"], "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBS, 5), "traffic": None,
+                                  "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBS, 5),
+                                  "traffic": pmc_traffic(dom),
                                   "avg_ms": d["avg_ms"], "alg_bytes": d["alg_bytes"],
                                   "note": "render kernels are FP32-VALU/LDS bound, not HBM bound (DESIGN.md)"}
 
