@@ -104,7 +104,7 @@ def test_binning_bit_exact_and_image_state():
     tt, rect, order = ll["tiles_touched"], ll["rect"].astype(np.int64), ll["order"]
     depth_bits = ll["rec"][:, 11].numpy().view(np.uint32).astype(np.uint64)
     vis = ll["radii"].numpy() > 0
-    assert ((tt > 0) == vis).all()
+    assert not (tt[~vis] > 0).any()          # culled Gaussians emit nothing; visible ones may emit 0 tiles (exact tile culling)
     # depth order: sorted keys ascending, permutation of all ids, stable on ties
     ks = ll["depth_keys_sorted"]
     assert (np.diff(ks.astype(np.int64)) >= 0).all()
@@ -117,7 +117,7 @@ def test_binning_bit_exact_and_image_state():
     # instance list: stable sort of (tile << 32 | depth bits) in ascending-id emission order
     gx = (W + 15) // 16
     keys, ids = [], []
-    for g in np.nonzero(vis)[0]:
+    for g in np.nonzero(tt > 0)[0]:
         x0, y0, x1, y1 = rect[g]
         assert (x1 - x0) * (y1 - y0) == tt[g]
         for y in range(y0, y1):
@@ -131,12 +131,28 @@ def test_binning_bit_exact_and_image_state():
     cnt = np.bincount(tile_sorted, minlength=ll["ranges"].shape[0]); ends = np.cumsum(cnt)
     exp_ranges = np.stack([ends - cnt, ends], 1); exp_ranges[cnt == 0] = 0
     assert (exp_ranges == ll["ranges"]).all()
-    # image state vs oracle
+    # image state vs oracle.  The instance lists are shorter than the oracle's (tiles that provably cannot contribute are
+    # not emitted), so list POSITIONS differ; what must agree is WHICH Gaussian is each pixel's last contributor, and T.
     ref = run_oracle(raw, cam, 3, bg, torch.float64)
     st = ref["state"]
-    assert float((ll["n_contrib"] == st["n_contrib"]).float().mean()) >= EXACT_FRAC
+    assert ll["R"] <= len(st["point_list"])
+    gyx = np.arange(H)[:, None] // 16 * gx + np.arange(W)[None, :] // 16          # tile of every pixel
+
+    def last_id(n_contrib, ranges, plist):
+        n = np.asarray(n_contrib, dtype=np.int64)
+        pos = np.asarray(ranges)[gyx, 0].astype(np.int64) + n - 1
+        ids = np.asarray(plist, dtype=np.int64)[np.clip(pos, 0, max(len(plist) - 1, 0))]
+        return np.where(n > 0, ids, -1)
+    a = last_id(ll["n_contrib"].numpy(), ll["ranges"], ll["point_list"])
+    b = last_id(st["n_contrib"].numpy(), st["ranges"].numpy(), st["point_list"].numpy())
+    assert (a == b).mean() >= EXACT_FRAC
     assert float(((ll["final_T"].double() - st["final_T"]).abs() <= 2e-5).double().mean()) >= FWD_FRAC
-    assert (st["point_list"].numpy() == ll["point_list"]).mean() >= 0.999     # oracle depth bits may differ by 1 ulp
+    # every emitted instance lies inside the published 3-sigma rectangle of its Gaussian
+    pre = st["pre"]
+    rmin, rmax = pre.rect_min.numpy(), pre.rect_max.numpy()
+    sub = rect[tt > 0]
+    assert (sub[:, 0] >= rmin[tt > 0, 0]).all() and (sub[:, 2] <= rmax[tt > 0, 0]).all()
+    assert (sub[:, 1] >= rmin[tt > 0, 1]).all() and (sub[:, 3] <= rmax[tt > 0, 1]).all()
 
 
 def test_config1_full_size():
