@@ -14,7 +14,8 @@
 __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ offsets_incl,
                                                         const uint32_t* __restrict__ tiles_touched,
-                                                        const ushort4* __restrict__ rect, uint32_t* __restrict__ tile_key,
+                                                        const ushort4* __restrict__ rect,
+                                                        const float4* __restrict__ rec, uint32_t* __restrict__ tile_key,
                                                         uint32_t* __restrict__ gauss_of_slot,
                                                         uint32_t* __restrict__ slot_start) {
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -25,12 +26,24 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
   uint32_t off = offsets_incl[j] - n;
   slot_start[g] = off;
   const ushort4 r = rect[g];
+  // same inputs (the stored record) and the same compiled row-interval routine as k_preprocess_fwd -> exactly n tiles
+  const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1];
+  const float q = -2.0f * r1.z;
+  const uint32_t end = off + n;
   for (int y = r.y; y < r.w; y++) {
-    for (int x = r.x; x < r.z; x++) {
+    const uint32_t iv = gsr_row_interval(r0.x, r0.y, r0.z, r0.w, r1.x, q, y, r.x, r.z);
+    const int lo = (int)(iv & 0xFFFFu), hi = (int)(iv >> 16);
+    for (int x = lo; x < hi && off < end; x++) {
       tile_key[off] = (uint32_t)(y * grid_x + x);
       gauss_of_slot[off] = g;
       off++;
     }
+  }
+  // belt and braces: if fewer tiles passed than were counted (cannot happen with one compiled test body), park the unused
+  // slots on this Gaussian's first tile with a sentinel Gaussian id that the render kernels treat as empty
+  for (; off < end; off++) {
+    tile_key[off] = (uint32_t)(r.y * grid_x + r.x);
+    gauss_of_slot[off] = 0xFFFFFFFFu;
   }
 }
 
@@ -62,7 +75,7 @@ void gsr_launch_emit(int P, int grid_x, const char* geom, const GsrGeomLayout& G
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
              (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
              (const uint32_t*)(geom + GL.tiles_touched), (const ushort4*)(geom + GL.rect),
-             (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start));
+             (const float4*)(geom + GL.rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start));
 }
 
 void gsr_launch_finalize(uint32_t R, const uint32_t* tile_sorted, const uint32_t* slot_sorted, char* bin,

@@ -161,6 +161,34 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
 #ifdef __HIPCC__
 __device__ __forceinline__ int gsr_lane() { return threadIdx.x & 63; }
 
+// Exact tile culling shared by preprocess (count) and emit (write).  Pixels that can blend a Gaussian satisfy
+// Q(d) = A dx^2 + 2B dx dy + C dy^2 <= q (q = -2 pmin, i.e. power >= pmin).  The part of that ellipse inside the horizontal
+// band of tile row ty (pixel centres 16ty .. 16ty+15) is convex, so the tile columns it reaches form ONE interval: its
+// x-extent is [x_lo(y*), x_hi(y**)] with x_hi/lo(y) = (-B y +- sqrt(A q - det y^2)) / A evaluated at the band-clamped
+// heights of the ellipse's right-/left-most points.  Returns the half-open column interval clipped to [cx0, cx1) packed as
+// lo | hi << 16 (lo >= hi: empty).  __noinline__: ONE compiled body, so the count and the emission agree bit for bit.
+__device__ __noinline__ uint32_t gsr_row_interval(float mx, float my, float A, float B, float C, float q, int ty, int cx0,
+                                                  int cx1) {
+  const float det = A * C - B * B;
+  const float hy = sqrtf(fmaxf(0.f, q * A / det)) * 1.0001f + 0.01f;       // ellipse half-height (+ slack)
+  const float yl = (float)(ty * GSR_TILE) - my, yh = yl + (float)(GSR_TILE - 1);
+  const float bl = fmaxf(yl, -hy), bh = fminf(yh, hy);
+  if (bl > bh) return 0u;                                                   // band misses the ellipse
+  const float yr = -B * sqrtf(fmaxf(0.f, q / (C * det)));                  // height of the right-most point (left-most: -yr)
+  const float y1 = fminf(bh, fmaxf(bl, yr)), y2 = fminf(bh, fmaxf(bl, -yr));
+  const float qa = q * 1.0002f + 0.002f;                                   // conservative slack >> fp32 error
+  const float xhi = (-B * y1 + sqrtf(fmaxf(0.f, A * qa - det * y1 * y1))) / A + 0.01f;
+  const float xlo = (-B * y2 - sqrtf(fmaxf(0.f, A * qa - det * y2 * y2))) / A - 0.01f;
+  // tile column t holds pixel centres 16t .. 16t+15 (relative to the mean: subtract mx)
+  const float lim = 1.0e9f;
+  int lo = (int)ceilf(fmaxf(-lim, (mx + xlo - (float)(GSR_TILE - 1)) / GSR_TILE));
+  int hi = (int)floorf(fminf(lim, (mx + xhi) / GSR_TILE)) + 1;
+  lo = max(lo, cx0);
+  hi = min(hi, cx1);
+  if (hi <= lo) return 0u;
+  return (uint32_t)lo | ((uint32_t)hi << 16);
+}
+
 // add with a DPP-shifted copy of itself (old = 0 for lanes without a source)
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float gsr_dpp_add(float v) {

@@ -113,10 +113,17 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
     if (__syncthreads_count(done) == 256) break;
     const uint32_t progress = range.x + (uint32_t)(r * FWD_BATCH + tid);
     if (progress < range.y) {
-      const size_t id = point_list[progress];
-      s0[tid] = rec[3 * id + 0];
-      s1[tid] = rec[3 * id + 1];
-      s2[tid] = rec[3 * id + 2];
+      const uint32_t id32 = point_list[progress];
+      if (id32 != 0xFFFFFFFFu) {
+        const size_t id = id32;
+        s0[tid] = rec[3 * id + 0];
+        s1[tid] = rec[3 * id + 1];
+        s2[tid] = rec[3 * id + 2];
+      } else {  // padding slot (see k_emit_instances): a record that can never pass the reject test
+        s0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s1[tid] = make_float4(0.f, 0.f, 3.0e38f, 0.f);
+        s2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     __syncthreads();
     const int n = toDo < FWD_BATCH ? toDo : FWD_BATCH;
@@ -244,10 +251,17 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
     __syncthreads();
     const int e_idx = toDo - 1 - (b * BWD_BATCH + tid);  // back-to-front staging (threads 0..127)
     if (tid < BWD_BATCH && e_idx >= 0) {
-      const size_t id = point_list[range.x + e_idx];
-      s0[tid] = rec[3 * id + 0];
-      s1[tid] = rec[3 * id + 1];
-      s2[tid] = rec[3 * id + 2];
+      const uint32_t id32 = point_list[range.x + e_idx];
+      if (id32 != 0xFFFFFFFFu) {
+        const size_t id = id32;
+        s0[tid] = rec[3 * id + 0];
+        s1[tid] = rec[3 * id + 1];
+        s2[tid] = rec[3 * id + 2];
+      } else {
+        s0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s1[tid] = make_float4(0.f, 0.f, 3.0e38f, 0.f);
+        s2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     // each wave clears its own slab (384 float4 / 64 lanes)
 #pragma unroll

@@ -114,23 +114,27 @@ def test_binning_bit_exact_and_image_state():
     # inclusive scan in depth order
     assert (np.cumsum(tt[order].astype(np.int64)) == ll["offsets"].astype(np.int64)).all()
     assert int(ll["offsets"][-1]) == ll["R"]
-    # instance list: stable sort of (tile << 32 | depth bits) in ascending-id emission order
+    # instance list.  Inside `rect` a tile is emitted only if the alpha >= 1/255 ellipse can reach it, so the expected list is
+    # rebuilt from the emitted (tile, Gaussian) pairs themselves: they must be distinct, lie inside rect, number
+    # tiles_touched per Gaussian, and be ordered exactly like a stable sort of (tile << 32 | depth bits) taken in
+    # ascending-id emission order (ties keep ascending Gaussian id).
     gx = (W + 15) // 16
-    keys, ids = [], []
-    for g in np.nonzero(tt > 0)[0]:
-        x0, y0, x1, y1 = rect[g]
-        assert (x1 - x0) * (y1 - y0) == tt[g]
-        for y in range(y0, y1):
-            for x in range(x0, x1):
-                keys.append((np.uint64(y * gx + x) << np.uint64(32)) | depth_bits[g]); ids.append(g)
-    keys = np.array(keys, dtype=np.uint64); ids = np.array(ids)
-    perm = np.argsort(keys, kind="stable")
-    assert len(ids) == ll["R"]
-    assert (ids[perm] == ll["point_list"]).all()
-    tile_sorted = (keys[perm] >> np.uint64(32)).astype(np.int64)
-    cnt = np.bincount(tile_sorted, minlength=ll["ranges"].shape[0]); ends = np.cumsum(cnt)
-    exp_ranges = np.stack([ends - cnt, ends], 1); exp_ranges[cnt == 0] = 0
-    assert (exp_ranges == ll["ranges"]).all()
+    pl, rg = ll["point_list"].astype(np.int64), ll["ranges"].astype(np.int64)
+    assert len(pl) == ll["R"] == int(tt.sum())
+    tile_of_pos = np.full(len(pl), -1, dtype=np.int64)
+    for t in range(rg.shape[0]):
+        tile_of_pos[rg[t, 0]:rg[t, 1]] = t
+    assert (tile_of_pos >= 0).all()                                            # ranges tile the list completely
+    assert (np.diff(rg[rg[:, 1] > rg[:, 0]].reshape(-1)) >= 0).all()          # and in tile order
+    pair = tile_of_pos * P + pl
+    assert len(np.unique(pair)) == len(pair)                                  # no duplicates
+    tyx = np.stack([tile_of_pos % gx, tile_of_pos // gx], 1)
+    assert ((tyx[:, 0] >= rect[pl, 0]) & (tyx[:, 0] < rect[pl, 2]) & (tyx[:, 1] >= rect[pl, 1]) & (tyx[:, 1] < rect[pl, 3])).all()
+    assert (np.bincount(pl, minlength=P) == tt).all()
+    key = (tile_of_pos.astype(np.uint64) << np.uint64(32)) | depth_bits[pl]
+    order_key = key.astype(object) * (2 ** 32) + pl                            # (tile, depth bits, id) as one integer
+    assert all(order_key[i] < order_key[i + 1] for i in range(len(order_key) - 1))
+    assert int(ll["ranges"][:, 1].max()) == ll["R"]
     # image state vs oracle.  The instance lists are shorter than the oracle's (tiles that provably cannot contribute are
     # not emitted), so list POSITIONS differ; what must agree is WHICH Gaussian is each pixel's last contributor, and T.
     ref = run_oracle(raw, cam, 3, bg, torch.float64)
