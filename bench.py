@@ -196,7 +196,11 @@ def main():
 
     torch.set_num_threads(host_threads())
     from scene_utils import init_from_env, Trainer
-    rank, world, local = init_from_env("nccl")
+    # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1 rehearse the N>1 path with several ranks on ONE card (no RCCL between them)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    rank, world, local = init_from_env(backend)
+    if os.environ.get("BENCH_SHARE_GPU"):
+        local = 0
     log(f"rank {os.environ.get('RANK', '0')} start; host threads {host_threads()} (cpu_count {os.cpu_count()})")
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         if rank == 0:

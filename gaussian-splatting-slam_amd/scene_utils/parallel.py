@@ -24,7 +24,7 @@ def init_from_env(backend: str | None = None):
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if backend == "nccl" and not os.environ.get("BENCH_SHARE_GPU"):
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
