@@ -31,10 +31,14 @@ static SsimWindow make_window() {
   return w;
 }
 
+// `partials` != NULL: the kernel also reduces sum(ssim) and sum(|img1-img2|) over its tile into partials[2*block .. +1]
+// (fixed in-block order; the host adds the per-block pairs in index order -> deterministic), which is all the fused
+// L1 + D-SSIM training loss needs; `ssim_map` may then be NULL.
 __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float C2, SsimWindow win,
                                                   const float* __restrict__ img1, const float* __restrict__ img2,
                                                   float* __restrict__ ssim_map, float* __restrict__ dm_dmu1,
-                                                  float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12) {
+                                                  float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
+                                                  float* __restrict__ partials) {
   __shared__ float sx[SH][SH + 1], sy[SH][SH + 1];
   __shared__ float hm[5][SH][ST + 1];
   const int tid = threadIdx.x;
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
   }
   __syncthreads();
   // vertical pass + SSIM
+  float acc_ssim = 0.f, acc_l1 = 0.f;
   for (int i = tid; i < ST * ST; i += 256) {
     const int r = i / ST, c = i - r * ST;
     const int gy = y0 + r, gx = x0 + c;
@@ -83,7 +88,9 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
     const float inv = 1.0f / (Cc * D);
     const float m = A * B * inv;
     const size_t o = plane + (size_t)gy * W + gx;
-    ssim_map[o] = m;
+    if (ssim_map) ssim_map[o] = m;
+    acc_ssim += m;
+    acc_l1 += fabsf(sx[r + SR][c + SR] - sy[r + SR][c + SR]);
     if (dm_dmu1) {
       // partials holding E[xx], E[yy], E[xy] fixed (sigma's depend on mu1 through -mu1^2, -mu1*mu2)
       dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - m * 2.f * mu1 / Cc + m * 2.f * mu1 / D;
@@ -91,11 +98,33 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
       dm_dsigma12[o] = 2.f * A * inv;
     }
   }
+  if (partials) {
+    __syncthreads();                               // hm is free now: reuse it for the block reduction
+    float* red = &hm[0][0][0];
+    red[tid] = acc_ssim;
+    red[256 + tid] = acc_l1;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+      if (tid < sft) {
+        red[tid] += red[tid + sft];
+        red[256 + tid] += red[256 + tid + sft];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      partials[2 * b] = red[0];
+      partials[2 * b + 1] = red[256];
+    }
+  }
 }
 
 // dL/dimg1 = w*(g dm_dmu1) + 2 x (w*(g dm_dsigma1_sq)) + y (w*(g dm_dsigma12)),   g = dL/dmap
+// dL_dmap == NULL: the upstream gradient of the map is the constant g_const (mean reduction), and g_l1 * sign(img1 - img2)
+// is added (the L1 term of the fused training loss).
 __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, SsimWindow win, const float* __restrict__ img1,
                                                   const float* __restrict__ img2, const float* __restrict__ dL_dmap,
+                                                  float g_const, float g_l1, const float* __restrict__ upstream,
                                                   const float* __restrict__ dm_dmu1,
                                                   const float* __restrict__ dm_dsigma1_sq,
                                                   const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
@@ -104,13 +133,18 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, SsimWindow win, 
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
   const size_t plane = (size_t)blockIdx.z * H * W;
+  if (upstream) {                                  // scalar dL/dloss lives on the device: no host round trip
+    const float u = upstream[0];
+    g_const *= u;
+    g_l1 *= u;
+  }
   for (int i = tid; i < SH * SH; i += 256) {
     const int r = i / SH, c = i - r * SH;
     const int gy = y0 + r - SR, gx = x0 + c - SR;
     float a = 0.f, b = 0.f, d = 0.f;
     if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
       const size_t o = plane + (size_t)gy * W + gx;
-      const float g = dL_dmap[o];
+      const float g = dL_dmap ? dL_dmap[o] : g_const;
       a = g * dm_dmu1[o];
       b = g * dm_dsigma1_sq[o];
       d = g * dm_dsigma12[o];
@@ -140,7 +174,10 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, SsimWindow win, 
       t0 += w * hm[0][r + k][c]; t1 += w * hm[1][r + k][c]; t2 += w * hm[2][r + k][c];
     }
     const size_t o = plane + (size_t)gy * W + gx;
-    dL_dimg1[o] = t0 + 2.f * img1[o] * t1 + img2[o] * t2;
+    const float x = img1[o], y = img2[o];
+    float out = t0 + 2.f * x * t1 + y * t2;
+    if (!dL_dmap) out += g_l1 * ((x > y) ? 1.f : ((x < y) ? -1.f : 0.f));      // torch.sign semantics (0 at equality)
+    dL_dimg1[o] = out;
   }
 }
 
@@ -159,8 +196,75 @@ int gsr_fused_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
   GSR_LAUNCH("ssim_fwd", k_ssim_fwd, grid, dim3(256), 0, st, H, W, C1, C2, win, img1, img2, ssim_map, dm_dmu1,
-             dm_dsigma1_sq, dm_dsigma12);
+             dm_dsigma1_sq, dm_dsigma12, (float*)nullptr);
   return gsr_check(hipGetLastError(), "ssim forward launch");
+}
+
+// Fused training loss of reference train.py:114-121: (1-lambda) * mean|img1-img2| + lambda * (1 - mean(ssim_map)).
+// Forward writes the three dm_* maps and per-block partial sums partials[2*nblocks] (ssim sum, L1 sum);
+// gsr_fused_loss_blocks() gives nblocks.  The caller adds the partials (in index order) and forms the scalar.
+int64_t gsr_fused_loss_blocks(int32_t planes, int32_t H, int32_t W) {
+  return (int64_t)((W + ST - 1) / ST) * ((H + ST - 1) / ST) * planes;
+}
+
+// one workgroup adds the per-block partial sums in a fixed order and forms the scalar loss
+__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ partials, long long nblk, float lambda,
+                                                       float inv_n, float* __restrict__ loss) {
+  __shared__ float red[512];
+  float a = 0.f, b = 0.f;
+  for (long long i = threadIdx.x; i < nblk; i += 256) {
+    a += partials[2 * i];
+    b += partials[2 * i + 1];
+  }
+  red[threadIdx.x] = a;
+  red[256 + threadIdx.x] = b;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) {
+      red[threadIdx.x] += red[threadIdx.x + sft];
+      red[256 + threadIdx.x] += red[256 + threadIdx.x + sft];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (1.0f - lambda) * (red[256] * inv_n) + lambda * (1.0f - red[0] * inv_n);
+}
+
+int gsr_fused_l1_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float C2, float lambda_dssim,
+                              const float* img1, const float* img2, float* dm_dmu1, float* dm_dsigma1_sq,
+                              float* dm_dsigma12, float* partials, float* loss, void* stream) {
+  if (planes <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !partials ||
+      !loss) {
+    gsr_set_error("fused_l1_ssim_forward: bad arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  static const SsimWindow win = make_window();
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  GSR_LAUNCH("loss_fwd", k_ssim_fwd, grid, dim3(256), 0, st, H, W, C1, C2, win, img1, img2, (float*)nullptr, dm_dmu1,
+             dm_dsigma1_sq, dm_dsigma12, partials);
+  const long long nblk = (long long)grid.x * grid.y * grid.z;
+  const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
+  GSR_LAUNCH("loss_finalize", k_loss_finalize, dim3(1), dim3(256), 0, st, (const float*)partials, nblk, lambda_dssim,
+             inv_n, loss);
+  return gsr_check(hipGetLastError(), "fused loss forward launch");
+}
+
+// dL/dimg1 = upstream[0] * dloss/dimg1 (`upstream`: DEVICE scalar dL/dloss, or NULL for 1).
+int gsr_fused_l1_ssim_backward(int32_t planes, int32_t H, int32_t W, float lambda_dssim, const float* img1,
+                               const float* img2, const float* upstream, const float* dm_dmu1,
+                               const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1, void* stream) {
+  if (planes <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) {
+    gsr_set_error("fused_l1_ssim_backward: bad arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  static const SsimWindow win = make_window();
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
+  GSR_LAUNCH("loss_bwd", k_ssim_bwd, grid, dim3(256), 0, st, H, W, win, img1, img2, (const float*)nullptr,
+             -lambda_dssim * inv_n, (1.0f - lambda_dssim) * inv_n, upstream, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+             dL_dimg1);
+  return gsr_check(hipGetLastError(), "fused loss backward launch");
 }
 
 int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2,
@@ -175,8 +279,8 @@ int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* i
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
-  GSR_LAUNCH("ssim_bwd", k_ssim_bwd, grid, dim3(256), 0, st, H, W, win, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq,
-             dm_dsigma12, dL_dimg1);
+  GSR_LAUNCH("ssim_bwd", k_ssim_bwd, grid, dim3(256), 0, st, H, W, win, img1, img2, dL_dmap, 0.f, 0.f,
+             (const float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
   return gsr_check(hipGetLastError(), "ssim backward launch");
 }
 

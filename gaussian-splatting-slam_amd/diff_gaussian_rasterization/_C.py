@@ -69,6 +69,10 @@ EXPORTS = {
                                         C.POINTER(C.c_void_p)]),
     "gsr_fused_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),
     "gsr_fused_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
+    "gsr_fused_loss_blocks": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gsr_fused_l1_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float] +
+                                  [C.c_void_p] * 8),
+    "gsr_fused_l1_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float] + [C.c_void_p] * 8),
     "gsr_adam_step": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "gsr_sparse_adam_step": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -33,3 +33,46 @@ def fused_ssim(img1, img2, padding="same", train=True):
     if padding != "same":
         raise NotImplementedError("only padding='same' (zero padding, as the reference's ssim()) is implemented")
     return FusedSSIMMap.apply(C1, C2, img1, img2, train).mean()
+
+
+class _FusedL1SSIMLoss(torch.autograd.Function):
+    """(1-l) * mean|img1-img2| + l * (1 - mean(ssim_map(img1, img2))): reference train.py:114-121 in three HIP launches
+    (forward + finalize, backward), no host synchronisation."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, lambda_dssim):
+        if not img1.is_cuda:
+            raise _C.GsrError("fused_l1_ssim_loss needs tensors on the HIP device (no CPU path)")
+        lib = _C.lib()
+        a = img1.detach().float().contiguous()
+        b = img2.detach().float().contiguous()
+        H, W = int(a.shape[-2]), int(a.shape[-1])
+        planes = a.numel() // (H * W)
+        parts = [torch.empty_like(a) for _ in range(3)]
+        nblk = int(lib.gsr_fused_loss_blocks(planes, H, W))
+        partials = torch.empty(nblk, 2, dtype=torch.float32, device=a.device)
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _C.check(lib.gsr_fused_l1_ssim_forward(planes, H, W, C1, C2, float(lambda_dssim), _C.ptr(a), _C.ptr(b),
+                                                   _C.ptr(parts[0]), _C.ptr(parts[1]), _C.ptr(parts[2]),
+                                                   _C.ptr(partials), _C.ptr(loss), _C._stream()))
+        ctx.save_for_backward(a, b, *parts)
+        ctx.lam = float(lambda_dssim)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.lib()
+        a, b, p0, p1, p2 = ctx.saved_tensors
+        H, W = int(a.shape[-2]), int(a.shape[-1])
+        planes = a.numel() // (H * W)
+        g = g.detach().float().contiguous()                # device scalar dL/dloss: read by the kernel, never by the host
+        out = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _C.check(lib.gsr_fused_l1_ssim_backward(planes, H, W, ctx.lam, _C.ptr(a), _C.ptr(b), _C.ptr(g), _C.ptr(p0),
+                                                    _C.ptr(p1), _C.ptr(p2), _C.ptr(out), _C._stream()))
+        return out, None, None
+
+
+def fused_l1_ssim_loss(img1, img2, lambda_dssim=0.2):
+    return _FusedL1SSIMLoss.apply(img1, img2, lambda_dssim)

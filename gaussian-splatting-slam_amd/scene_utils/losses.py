@@ -55,8 +55,7 @@ def training_loss(image, gt_image, lambda_dssim=0.2):
 
 
 def training_loss_fused(image, gt_image, lambda_dssim=0.2):
-    """reference train.py:114-121, FUSED_SSIM_AVAILABLE branch: `fused_ssim(image.unsqueeze(0), gt.unsqueeze(0))` runs in the
-    HIP kernels of csrc/ssim.hip (no CPU path)."""
-    from fused_ssim import fused_ssim
-    Ll1 = l1_loss(image, gt_image)
-    return (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - fused_ssim(image.unsqueeze(0), gt_image.unsqueeze(0)))
+    """reference train.py:114-121 (L1 + D-SSIM) as ONE fused HIP forward and ONE fused backward (csrc/ssim.hip; SURVEY 8(f) f3
+    "Fused L1 + SSIM loss"); no CPU path.  The separate `fused_ssim()` of the reference's interface stays available."""
+    from fused_ssim import fused_l1_ssim_loss
+    return fused_l1_ssim_loss(image, gt_image, lambda_dssim)

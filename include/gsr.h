@@ -146,6 +146,18 @@ int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* i
                             const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq,
                             const float* dm_dsigma12, float* dL_dimg1, void* stream);
 
+/* Fused training loss of reference train.py:114-121, (1-l)*mean|a-b| + l*(1-mean(ssim)) (SURVEY.md 8(f) f3 "Fused L1 + SSIM
+ * loss"): forward writes the dm_* maps and per-block partial sums partials[2*gsr_fused_loss_blocks()] = (sum ssim, sum |a-b|);
+ * a one-workgroup finalize adds them in a fixed order into the device scalar `loss`; backward reads dL/dloss from the device. */
+int64_t gsr_fused_loss_blocks(int32_t planes, int32_t H, int32_t W);
+int gsr_fused_l1_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float C2, float lambda_dssim,
+                              const float* img1, const float* img2, float* dm_dmu1, float* dm_dsigma1_sq,
+                              float* dm_dsigma12, float* partials, float* loss /*device scalar*/, void* stream);
+int gsr_fused_l1_ssim_backward(int32_t planes, int32_t H, int32_t W, float lambda_dssim, const float* img1,
+                               const float* img2, const float* upstream /*device scalar dL/dloss or NULL*/,
+                               const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                               float* dL_dimg1, void* stream);
+
 /* One-launch Adam over up to 8 tensors.  Dense = torch.optim.Adam semantics (reference scene/gaussian_model.py:169-170
  * default optimizer); sparse = `SparseGaussianAdam.step(visibility, N)` (reference train.py:37-41,173-176): rows of
  * invisible Gaussians untouched, no bias correction.  Array arguments are HOST arrays of `count` entries; betas / eps are

@@ -96,3 +96,28 @@ def test_sparse_adam_touches_only_visible_rows():
         assert torch.allclose(d.detach().cpu(), c, rtol=2e-6, atol=1e-7), err
         inv = ~vis
         assert torch.equal(d.detach().cpu()[inv], p0[inv])       # invisible rows bit-identical
+
+
+@pytest.mark.parametrize("shape,lam", [((3, 67, 45), 0.2), ((3, 270, 480), 0.2), ((3, 33, 32), 0.7)])
+def test_fused_l1_ssim_loss_matches_reference_loss(shape, lam):
+    """The fused training loss against reference train.py:114-121 evaluated with the pure-PyTorch l1_loss / ssim restatements
+    (float64 on the CPU), value and gradient."""
+    from fused_ssim import fused_l1_ssim_loss
+    gen = torch.Generator().manual_seed(sum(shape))
+    a = torch.rand(*shape, generator=gen, dtype=torch.float64)
+    b = (a + 0.1 * torch.randn(*shape, generator=gen, dtype=torch.float64)).clamp(0, 1)
+    b[:, :4, :4] = a[:, :4, :4]                              # exact ties: sign(0) = 0 like torch
+    a_ref = a.clone().requires_grad_(True)
+    ref = losses.training_loss(a_ref, b, lam)
+    ref.backward()
+    a_gpu = a.float().cuda().requires_grad_(True)
+    val = fused_l1_ssim_loss(a_gpu, b.float().cuda(), lam)
+    (3.0 * val).backward()                                  # non-unit upstream gradient
+    assert abs(val.item() - ref.item()) <= 2e-6
+    g, g_ref = a_gpu.grad.cpu().double(), 3.0 * a_ref.grad
+    assert (g - g_ref).norm() / g_ref.norm() <= 1e-4
+    # bitwise reproducible
+    a2 = a.float().cuda().requires_grad_(True)
+    v2 = fused_l1_ssim_loss(a2, b.float().cuda(), lam)
+    (3.0 * v2).backward()
+    assert v2.item() == val.item() and torch.equal(a2.grad, a_gpu.grad)
