@@ -50,19 +50,30 @@ class Trainer:
         self.densify = dict(extent=extent, from_iter=from_iter, until_iter=until_iter, interval=interval,
                             reset=opacity_reset_interval, thr=grad_threshold, min_opacity=min_opacity, seed=seed)
 
-    def step(self, view_idx: int):
-        cam = self.cameras[view_idx]
-        pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh)
-        image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
-        loss = self.loss_fn(image, self.gt_images[view_idx], self.lambda_dssim)
-        if self.depth_weight > 0 and self.depth_targets is not None:
-            loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[view_idx]).mean()
-        loss.backward()
+    def step(self, view_idx):
+        """One optimizer step.  `view_idx`: one view (the reference's batch-1 step) or a list of views whose gradients are
+        accumulated locally before the single cross-rank exchange and the single Adam step (gradient accumulation)."""
+        views = list(view_idx) if isinstance(view_idx, (list, tuple)) else [view_idx]
+        for n, v in enumerate(views):
+            cam = self.cameras[v]
+            pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh)
+            image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
+            loss = self.loss_fn(image, self.gt_images[v], self.lambda_dssim)
+            if self.depth_weight > 0 and self.depth_targets is not None:
+                loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[v]).mean()
+            if len(views) > 1:
+                loss = loss / len(views)
+            loss.backward()                                                                      # .grad accumulates
+            with torch.no_grad():
+                # densification statistics are per-view: norm BEFORE any cross-rank reduction (SURVEY 8e)
+                self.model.add_densification_stats(vsp, vis, radii)                          # train.py:159-160
+            if n + 1 < len(views):
+                vis_any = vis if n == 0 else (vis_any | vis)
+        if len(views) > 1:
+            vis = vis_any | vis
         self.iteration += 1
         self.last = dict(loss=loss.detach(), image=image.detach(), radii=radii)
         with torch.no_grad():
-            # densification statistics are per-view: norm BEFORE any cross-rank reduction
-            self.model.add_densification_stats(vsp, vis, radii)                              # train.py:159-160
             if self.bucket is not None:
                 self.bucket.all_reduce_mean(self.world)
             if self.densify is not None:
