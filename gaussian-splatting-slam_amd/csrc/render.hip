@@ -82,7 +82,9 @@ extern "C" int gsr_debug_wave_reduce(const float* in640, float* out10, void* str
   return gsr_check(hipGetLastError(), "debug wave reduce");
 }
 
+#ifndef FWD_BATCH
 #define FWD_BATCH 256
+#endif
 #define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 
 __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, const uint2* __restrict__ ranges,
@@ -174,7 +176,9 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   }
 }
 
+#ifndef BWD_BATCH
 #define BWD_BATCH 128   // entries staged per round in the backward (4 per-wave gradient slabs must fit LDS)
+#endif
 
 // DEPTH = false: no gradient arrives on the inverse-depth image (the usual training step): its recurrence and its
 // reduction are compiled out.

@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (must be imported first: the library shares torch's HIP runtime - same SONAME)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")   # GSR_LIB: A/B a variant build
 
 c_float_p = C.POINTER(C.c_float)
 
