@@ -154,7 +154,35 @@ __global__ __launch_bounds__(256) void k_densify_apply(int P, DensTensors t, con
   }
 }
 
+// add_densification_stats (reference scene/gaussian_model.py:431-433) + the max_radii2D update of train.py:159 in one pass:
+// for visible Gaussians (radii > 0): accum += ||dL/dmeans2D.xy||, denom += 1, max_radii = max(max_radii, radii).
+__global__ __launch_bounds__(256) void k_densify_stats(int P, const float* __restrict__ grad_means2D,
+                                                       const int32_t* __restrict__ radii, float* __restrict__ accum,
+                                                       float* __restrict__ denom, float* __restrict__ max_radii) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const int r = radii[i];
+  if (r > 0) {
+    const float gx = grad_means2D[3 * (size_t)i], gy = grad_means2D[3 * (size_t)i + 1];
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+    max_radii[i] = fmaxf(max_radii[i], (float)r);
+  }
+}
+
 extern "C" {
+
+int gsr_densification_stats(int64_t P, const float* grad_means2D, const int32_t* radii, float* xyz_gradient_accum,
+                            float* denom, float* max_radii2D, void* stream) {
+  if (P < 0 || (P > 0 && (!grad_means2D || !radii || !xyz_gradient_accum || !denom || !max_radii2D))) {
+    gsr_set_error("densification_stats: bad arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (P == 0) return 0;
+  GSR_LAUNCH("densify_stats", k_densify_stats, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+             (int)P, grad_means2D, radii, xyz_gradient_accum, denom, max_radii2D);
+  return gsr_check(hipGetLastError(), "densification_stats launch");
+}
 
 size_t gsr_densify_workspace_bytes(int64_t P) {
   const size_t p = (size_t)(P < 1 ? 1 : P);

@@ -78,6 +78,7 @@ EXPORTS = {
     "gsr_sparse_adam_step": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                        C.c_void_p]),
+    "gsr_densification_stats": (C.c_int, [C.c_int64] + [C.c_void_p] * 6),
     "gsr_densify_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gsr_densify_plan": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64),

@@ -140,12 +140,22 @@ def training_setup(self, optimizer="hip", percent_dense=0.01, **lrs):
 
 
 def add_densification_stats(self, viewspace_point_tensor, update_filter, radii=None):
-    """reference gaussian_model.py:431-433 (+ train.py:159 max_radii2D), written without boolean-mask indexing (no
-    device->host sync): the gradient and the radii are zero where update_filter is False."""
+    """reference gaussian_model.py:431-433 (+ train.py:159 max_radii2D when `radii` is given).  On the HIP device this is one
+    kernel (csrc/densify.hip k_densify_stats; update_filter == radii > 0 as in the reference's call); the CPU branch
+    (gloo tests) is the same arithmetic without boolean-mask indexing."""
     with torch.no_grad():
+        g = viewspace_point_tensor.grad
+        if g.is_cuda and radii is not None:
+            from diff_gaussian_rasterization import _C
+            P = int(g.shape[0])
+            with torch.cuda.device(g.device):
+                _C.check(_C.lib().gsr_densification_stats(P, _C.ptr(g.contiguous()), _C.ptr(radii.contiguous()),
+                                                          _C.ptr(self.xyz_gradient_accum), _C.ptr(self.denom),
+                                                          _C.ptr(self.max_radii2D), _C._stream()))
+            return
         if radii is not None:
             torch.maximum(self.max_radii2D, radii.float(), out=self.max_radii2D)
-        self.xyz_gradient_accum += torch.norm(viewspace_point_tensor.grad[:, :2], dim=-1, keepdim=True) * update_filter[:, None]
+        self.xyz_gradient_accum += torch.norm(g[:, :2], dim=-1, keepdim=True) * update_filter[:, None]
         self.denom += update_filter[:, None]
 
 

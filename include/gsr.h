@@ -176,6 +176,10 @@ int gsr_sparse_adam_step(int32_t count, float* const* params, const float* const
  * apply: writes the new arrays in the reference's order [kept originals][clones][children copy 0][children copy 1];
  * in_ptrs / out_ptrs are HOST arrays of 18 device pointers: (xyz, f_dc, f_rest, opacity, scaling, rotation) x
  * (value, exp_avg, exp_avg_sq); moments may be NULL.  New size = keep + clone + 2*child. */
+/* add_densification_stats (reference scene/gaussian_model.py:431-433) + max_radii2D update (train.py:159), one pass:
+ * where radii > 0: accum += ||grad_means2D.xy||, denom += 1, max_radii2D = max(max_radii2D, radii). */
+int gsr_densification_stats(int64_t P, const float* grad_means2D, const int32_t* radii, float* xyz_gradient_accum,
+                            float* denom, float* max_radii2D, void* stream);
 size_t gsr_densify_workspace_bytes(int64_t P);
 int gsr_densify_plan(int64_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling_raw,
                      const float* opacity_raw, float max_grad, float min_opacity, float extent, float percent_dense,

@@ -123,3 +123,27 @@ def test_training_with_densification_schedule():
         assert torch.isfinite(out["loss"])
     assert len(set(sizes)) > 2
     assert model.xyz_gradient_accum.shape[0] == sizes[-1]
+
+
+def test_densification_stats_kernel_matches_reference_lines():
+    """k_densify_stats against reference scene/gaussian_model.py:431-433 + train.py:159 written with torch ops."""
+    gen = torch.Generator().manual_seed(5)
+    P = 5003
+    m = GaussianModel.from_raw(make_gaussians(P, 0, seed=1).to("cuda"))
+    m.training_setup(optimizer="hip")
+    m.xyz_gradient_accum = torch.rand(P, 1, generator=gen).cuda()
+    m.denom = torch.randint(0, 5, (P, 1), generator=gen).float().cuda()
+    m.max_radii2D = (torch.rand(P, generator=gen) * 30).cuda()
+    acc0, den0, mr0 = m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone()
+    radii = torch.randint(0, 60, (P,), generator=gen, dtype=torch.int32)
+    radii[torch.rand(P, generator=gen) < 0.4] = 0
+    radii = radii.cuda()
+    vsp = torch.zeros(P, 3, device="cuda", requires_grad=True)
+    vsp.grad = torch.randn(P, 3, generator=gen).cuda()
+    vis = radii > 0
+    m.add_densification_stats(vsp, vis, radii)
+    acc0[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)            # gaussian_model.py:432
+    den0[vis] += 1                                                              # :433
+    mr0[vis] = torch.max(mr0[vis], radii[vis].float())                          # train.py:159
+    assert torch.allclose(m.xyz_gradient_accum, acc0, rtol=1e-6, atol=1e-7)
+    assert torch.equal(m.denom, den0) and torch.equal(m.max_radii2D, mr0)
