@@ -189,21 +189,4 @@ __device__ __noinline__ uint32_t gsr_row_interval(float mx, float my, float A, f
   return (uint32_t)lo | ((uint32_t)hi << 16);
 }
 
-// add with a DPP-shifted copy of itself (old = 0 for lanes without a source)
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float gsr_dpp_add(float v) {
-  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
-  return v + __int_as_float(t);
-}
-// Full-wave (64-lane) sum; the total is valid in lane 63 only.  gfx9 DPP scan: row_shr 1,2,4,8 then
-// row_bcast15 / row_bcast31.
-__device__ __forceinline__ float gsr_wave_sum_to_lane63(float v) {
-  v = gsr_dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
-  v = gsr_dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
-  v = gsr_dpp_add<0x114, 0xf, 0xf>(v);  // row_shr:4
-  v = gsr_dpp_add<0x118, 0xf, 0xf>(v);  // row_shr:8
-  v = gsr_dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 -> rows 1,3
-  v = gsr_dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31 -> rows 2,3
-  return v;
-}
 #endif

@@ -337,8 +337,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
   }
   radii[idx] = out_radius;
   tiles_touched[idx] = out_tiles;
-  depth_key[idx] = out_key;
-  order[idx] = (uint32_t)idx;
+  depth_key[idx] = out_key;   // `order` is not written: the depth sort takes value = index on its first pass
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -344,3 +344,18 @@ def test_wave_reduction_primitive():
         _C.check(lib.gsr_debug_wave_reduce(_C.ptr(xin), _C.ptr(out), _C._stream()))
         torch.cuda.synchronize()
         assert torch.equal(out.cpu(), x.sum(dim=1)), (out.cpu(), x.sum(dim=1))
+
+
+def test_config4_code_path_small():
+    """BASELINE configs[3] code path (anti-aliasing + inverse-depth gradient, tile grid wider than 8 bits' worth of tiles
+    per row like 4K: 3840/16 = 240 columns) at a size the oracle handles: a 3840x32 strip."""
+    raw = make_gaussians(2500, 3, seed=61, scale_factor=1.2)
+    raw.xyz[:, 2] *= 0.05                                      # flatten the cloud so the wide strip is well covered
+    cam = look_at_camera((0.0, -3.0, 0.0), (0, 0, 0), (0, 0, 1), 1.9, 3840, 32)
+    bg = torch.tensor([0.1, 0.0, 0.2])
+    gc, gd = upstream_grads(32, 3840)
+    ref = run_oracle(raw, cam, 3, bg, torch.float64, antialiasing=True, gc=gc, gd=gd)
+    out = run_hip(raw, cam, 3, bg, antialiasing=True, gc=gc, gd=gd)
+    assert int((ref["radii"] > 0).sum()) > 500
+    check_forward(out, ref)
+    check_grads(out, ref)
