@@ -56,46 +56,62 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
     sy[r][c] = b;
   }
   __syncthreads();
-  // horizontal pass: SH rows x ST columns
-  for (int i = tid; i < SH * ST; i += 256) {
-    const int r = i / ST, c = i - r * ST;
-    float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+  // horizontal pass: SH rows x ST columns, FOUR adjacent columns per thread: the 14 taps they share are read from LDS once
+  // (sliding window) instead of 11 per output
+  for (int i = tid; i < SH * (ST / 4); i += 256) {
+    const int r = i / (ST / 4), c0 = (i - r * (ST / 4)) * 4;
+    float xa[14], ya[14];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float w = win.g[k], a = sx[r][c + k], b = sy[r][c + k];
-      m1 += w * a; m2 += w * b; s11 += w * a * a; s22 += w * b * b; s12 += w * a * b;
+    for (int k = 0; k < 14; k++) { xa[k] = sx[r][c0 + k]; ya[k] = sy[r][c0 + k]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) {
+        const float w = win.g[k], a = xa[j + k], b = ya[j + k];
+        m1 += w * a; m2 += w * b; s11 += w * a * a; s22 += w * b * b; s12 += w * a * b;
+      }
+      hm[0][r][c0 + j] = m1; hm[1][r][c0 + j] = m2; hm[2][r][c0 + j] = s11; hm[3][r][c0 + j] = s22; hm[4][r][c0 + j] = s12;
     }
-    hm[0][r][c] = m1; hm[1][r][c] = m2; hm[2][r][c] = s11; hm[3][r][c] = s22; hm[4][r][c] = s12;
   }
   __syncthreads();
-  // vertical pass + SSIM
+  // vertical pass + SSIM: each thread owns column c and FOUR adjacent rows (14 shared taps per moment)
   float acc_ssim = 0.f, acc_l1 = 0.f;
-  for (int i = tid; i < ST * ST; i += 256) {
-    const int r = i / ST, c = i - r * ST;
-    const int gy = y0 + r, gx = x0 + c;
-    if (gy >= H || gx >= W) continue;
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  {
+    const int c = tid & (ST - 1), r0 = (tid / ST) * 4;
+    float col[5][14];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float w = win.g[k];
-      mu1 += w * hm[0][r + k][c]; mu2 += w * hm[1][r + k][c]; e11 += w * hm[2][r + k][c];
-      e22 += w * hm[3][r + k][c]; e12 += w * hm[4][r + k][c];
-    }
-    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-    const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
-    const float A = 2.f * mu12 + C1, B = 2.f * sigma12 + C2;
-    const float Cc = mu1_sq + mu2_sq + C1, D = sigma1_sq + sigma2_sq + C2;
-    const float inv = 1.0f / (Cc * D);
-    const float m = A * B * inv;
-    const size_t o = plane + (size_t)gy * W + gx;
-    if (ssim_map) ssim_map[o] = m;
-    acc_ssim += m;
-    acc_l1 += fabsf(sx[r + SR][c + SR] - sy[r + SR][c + SR]);
-    if (dm_dmu1) {
-      // partials holding E[xx], E[yy], E[xy] fixed (sigma's depend on mu1 through -mu1^2, -mu1*mu2)
-      dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - m * 2.f * mu1 / Cc + m * 2.f * mu1 / D;
-      dm_dsigma1_sq[o] = -m / D;
-      dm_dsigma12[o] = 2.f * A * inv;
+    for (int q = 0; q < 5; q++)
+#pragma unroll
+      for (int k = 0; k < 14; k++) col[q][k] = hm[q][r0 + k][c];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int r = r0 + j;
+      const int gy = y0 + r, gx = x0 + c;
+      if (gy >= H || gx >= W) continue;
+      float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) {
+        const float w = win.g[k];
+        mu1 += w * col[0][j + k]; mu2 += w * col[1][j + k]; e11 += w * col[2][j + k];
+        e22 += w * col[3][j + k]; e12 += w * col[4][j + k];
+      }
+      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+      const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
+      const float A = 2.f * mu12 + C1, B = 2.f * sigma12 + C2;
+      const float Cc = mu1_sq + mu2_sq + C1, D = sigma1_sq + sigma2_sq + C2;
+      const float inv = 1.0f / (Cc * D);
+      const float m = A * B * inv;
+      const size_t o = plane + (size_t)gy * W + gx;
+      if (ssim_map) ssim_map[o] = m;
+      acc_ssim += m;
+      acc_l1 += fabsf(sx[r + SR][c + SR] - sy[r + SR][c + SR]);
+      if (dm_dmu1) {
+        // partials holding E[xx], E[yy], E[xy] fixed (sigma's depend on mu1 through -mu1^2, -mu1*mu2)
+        dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - m * 2.f * mu1 / Cc + m * 2.f * mu1 / D;
+        dm_dsigma1_sq[o] = -m / D;
+        dm_dsigma12[o] = 2.f * A * inv;
+      }
     }
   }
   if (partials) {
@@ -152,32 +168,46 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, SsimWindow win, 
     sa[0][r][c] = a; sa[1][r][c] = b; sa[2][r][c] = d;
   }
   __syncthreads();
-  for (int i = tid; i < SH * ST; i += 256) {
-    const int r = i / ST, c = i - r * ST;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+  for (int i = tid; i < SH * (ST / 4); i += 256) {           // horizontal pass, 4 adjacent columns per thread
+    const int r = i / (ST / 4), c0 = (i - r * (ST / 4)) * 4;
+    float v0[14], v1[14], v2[14];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float w = win.g[k];
-      t0 += w * sa[0][r][c + k]; t1 += w * sa[1][r][c + k]; t2 += w * sa[2][r][c + k];
+    for (int k = 0; k < 14; k++) { v0[k] = sa[0][r][c0 + k]; v1[k] = sa[1][r][c0 + k]; v2[k] = sa[2][r][c0 + k]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) {
+        const float w = win.g[k];
+        t0 += w * v0[j + k]; t1 += w * v1[j + k]; t2 += w * v2[j + k];
+      }
+      hm[0][r][c0 + j] = t0; hm[1][r][c0 + j] = t1; hm[2][r][c0 + j] = t2;
     }
-    hm[0][r][c] = t0; hm[1][r][c] = t1; hm[2][r][c] = t2;
   }
   __syncthreads();
-  for (int i = tid; i < ST * ST; i += 256) {
-    const int r = i / ST, c = i - r * ST;
-    const int gy = y0 + r, gx = x0 + c;
-    if (gy >= H || gx >= W) continue;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+  {                                                            // vertical pass, 4 adjacent rows per thread
+    const int c = tid & (ST - 1), r0 = (tid / ST) * 4;
+    float col[3][14];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float w = win.g[k];
-      t0 += w * hm[0][r + k][c]; t1 += w * hm[1][r + k][c]; t2 += w * hm[2][r + k][c];
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int k = 0; k < 14; k++) col[q][k] = hm[q][r0 + k][c];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int gy = y0 + r0 + j, gx = x0 + c;
+      if (gy >= H || gx >= W) continue;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) {
+        const float w = win.g[k];
+        t0 += w * col[0][j + k]; t1 += w * col[1][j + k]; t2 += w * col[2][j + k];
+      }
+      const size_t o = plane + (size_t)gy * W + gx;
+      const float x = img1[o], y = img2[o];
+      float out = t0 + 2.f * x * t1 + y * t2;
+      if (!dL_dmap) out += g_l1 * ((x > y) ? 1.f : ((x < y) ? -1.f : 0.f));      // torch.sign semantics (0 at equality)
+      dL_dimg1[o] = out;
     }
-    const size_t o = plane + (size_t)gy * W + gx;
-    const float x = img1[o], y = img2[o];
-    float out = t0 + 2.f * x * t1 + y * t2;
-    if (!dL_dmap) out += g_l1 * ((x > y) ? 1.f : ((x < y) ? -1.f : 0.f));      // torch.sign semantics (0 at equality)
-    dL_dimg1[o] = out;
   }
 }
 
