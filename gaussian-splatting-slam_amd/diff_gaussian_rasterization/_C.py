@@ -182,3 +182,88 @@ def fusedssim_backward(C1, C2, img1, img2, dL_dmap, partials=None):
         check(lib().gsr_fused_ssim_backward(planes, H, W, ptr(img1), ptr(img2), ptr(g), ptr(partials[0]),
                                             ptr(partials[1]), ptr(partials[2]), ptr(out), _stream()))
     return out
+
+
+# ---- the low-level call forms of the absent module's `_C` (SURVEY.md 8b "Native surface"; nothing in the reference calls them
+# directly, they are kept so code written against the published extension keeps working) ----
+def rasterize_gaussians(bg, means3D, colors_precomp, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos, prefiltered,
+                        antialiasing, debug):
+    """-> (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer, invdepth[1,H,W]); empty tensors stand
+    for absent inputs, as in the published extension."""
+    import diff_gaussian_rasterization as dgr
+
+    def opt(t):
+        return None if (t is None or t.numel() == 0) else t.detach().float().contiguous()
+    rs = dgr.GaussianRasterizationSettings(int(image_height), int(image_width), float(tanfovx), float(tanfovy), bg,
+                                           float(scale_modifier), viewmatrix, projmatrix, int(degree), campos,
+                                           bool(prefiltered), bool(debug), bool(antialiasing))
+    dev = means3D.device
+    P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
+    m3, col, op, sc, ro, cov, shs = opt(means3D), opt(colors_precomp), opt(opacity), opt(scales), opt(rotations), \
+        opt(cov3D_precomp), opt(sh)
+    l = lib()
+    with torch.cuda.device(dev):
+        s, keep = dgr._settings_struct(rs, dev)
+        g = dgr._gauss_struct(P, m3, None, shs, col, op, sc, ro, cov)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        geom = torch.empty(l.gsr_geometry_state_bytes(P), dtype=torch.uint8, device=dev)
+        img = torch.empty(l.gsr_image_state_bytes(W, H), dtype=torch.uint8, device=dev)
+        R = check(l.gsr_forward_prepare(C.byref(s), C.byref(g), ptr(geom), geom.numel(), ptr(radii), _stream()))
+        binning = torch.empty(l.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
+        check(l.gsr_forward_render(C.byref(s), C.byref(g), ptr(geom), ptr(binning), binning.numel(), R, ptr(img),
+                                   img.numel(), ptr(color), ptr(invdepth), 1, _stream()))
+    return R, color, radii, geom, binning, img, invdepth
+
+
+def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, opacities, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, dL_dcolor, dL_dinvdepth, sh, degree,
+                                 campos, geomBuffer, num_rendered, binningBuffer, imgBuffer, antialiasing, debug):
+    """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
+    dL_dscales[P,3], dL_drotations[P,4]) - the published order; absent inputs give empty gradient tensors."""
+    import diff_gaussian_rasterization as dgr
+
+    def opt(t):
+        return None if (t is None or t.numel() == 0) else t.detach().float().contiguous()
+    dev = means3D.device
+    P = int(means3D.shape[0])
+    H, W = int(dL_dcolor.shape[-2]), int(dL_dcolor.shape[-1])
+    rs = dgr.GaussianRasterizationSettings(H, W, float(tanfovx), float(tanfovy), bg, float(scale_modifier), viewmatrix,
+                                           projmatrix, int(degree), campos, False, bool(debug), bool(antialiasing))
+    m3, col, op, sc, ro, cov, shs = opt(means3D), opt(colors_precomp), opt(opacities), opt(scales), opt(rotations), \
+        opt(cov3D_precomp), opt(sh)
+    l = lib()
+
+    def like(t, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=dev) if t is not None else None
+    with torch.cuda.device(dev):
+        s, keep = dgr._settings_struct(rs, dev)
+        g = dgr._gauss_struct(P, m3, None, shs, col, op, sc, ro, cov)
+        d_m3 = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        d_m2 = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        d_op = torch.empty(P, 1, dtype=torch.float32, device=dev)
+        d_sh, d_col = like(shs, *(shs.shape if shs is not None else ())), like(col, P, 3)
+        d_sc, d_ro, d_cov = like(sc, P, 3), like(ro, P, 4), like(cov, P, 6)
+        scratch = torch.empty(l.gsr_backward_scratch_bytes(P, int(num_rendered)), dtype=torch.uint8, device=dev)
+        gr = gsr_grads(*[None if t is None else t.data_ptr() for t in (d_m3, d_m2, None, d_sh, d_col, d_op, d_sc, d_ro, d_cov)])
+        check(l.gsr_backward(C.byref(s), C.byref(g), ptr(radii), ptr(geomBuffer), ptr(binningBuffer), ptr(imgBuffer),
+                             int(num_rendered), ptr(opt(dL_dcolor)), ptr(opt(dL_dinvdepth)), ptr(scratch), scratch.numel(),
+                             C.byref(gr), _stream()))
+    e = torch.empty(0, device=dev)
+    return (d_m2, d_col if d_col is not None else e, d_op, d_m3, d_cov if d_cov is not None else e,
+            d_sh if d_sh is not None else e, d_sc if d_sc is not None else e, d_ro if d_ro is not None else e)
+
+
+def mark_visible(positions, viewmatrix, projmatrix=None):
+    """bool[P] (published `_C.mark_visible(positions, viewmatrix, projmatrix)`; the projection matrix is not needed for the
+    near-plane test)."""
+    positions = positions.detach().float().contiguous()
+    P = int(positions.shape[0])
+    present = torch.zeros(P, dtype=torch.uint8, device=positions.device)
+    if P:
+        vm = viewmatrix.detach().float().contiguous().to(positions.device)
+        with torch.cuda.device(positions.device):
+            check(lib().gsr_mark_visible(P, ptr(positions), ptr(vm), ptr(present), _stream()))
+    return present.bool()

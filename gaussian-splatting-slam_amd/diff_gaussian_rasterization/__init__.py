@@ -40,6 +40,16 @@ class GaussianRasterizationSettings(NamedTuple):
 last_call_stats = {"num_rendered": 0}
 
 
+def _dump(path, rs, *tensors):
+    """debug=True failure snapshot (reference README.md:168-169 `snapshot_fw.dump` / `snapshot_bw.dump`)."""
+    try:
+        torch.save({"settings": {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in rs._asdict().items()},
+                    "tensors": [None if t is None else t.detach().cpu() for t in tensors]}, path)
+        print(f"\nAn error occured in the rasterizer. Writing {path} for debugging.")
+    except Exception as e:  # never mask the original error
+        print(f"could not write {path}: {e}")
+
+
 def _f32c(t):
     if t is None or t.numel() == 0:
         return None
@@ -100,12 +110,18 @@ class _RasterizeGaussians(torch.autograd.Function):
             g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
             geom = torch.empty(lib.gsr_geometry_state_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(lib.gsr_image_state_bytes(W, H), dtype=torch.uint8, device=dev)
-            R = _C.check(lib.gsr_forward_prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
-                                                 _stream()))
-            binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
-            _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning), binning.numel(), R,
-                                            _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invdepth),
-                                            1 if needs_grad else 0, _stream()))
+            try:
+                R = _C.check(lib.gsr_forward_prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
+                                                     _stream()))
+                binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
+                _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning), binning.numel(),
+                                                R, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invdepth),
+                                                1 if needs_grad else 0, _stream()))
+            except _C.GsrError:
+                if rs.debug:   # reference README.md:168-169: with --debug a failing rasterizer call dumps its inputs
+                    _dump("snapshot_fw.dump", rs, means3D, dc, sh, colors_precomp, opacities, scales, rotations,
+                          cov3D_precomp)
+                raise
         last_call_stats["num_rendered"] = int(R)
         ctx.raster_settings = rs
         ctx.num_rendered = R
@@ -151,9 +167,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 scratch = torch.empty(lib.gsr_backward_scratch_bytes(P, R), dtype=torch.uint8, device=dev)
                 gr = _C.gsr_grads(*[None if t is None else t.data_ptr() for t in
                                     (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov)])
-                _C.check(lib.gsr_backward(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom), _C.ptr(binning),
-                                          _C.ptr(img), R, _C.ptr(grad_color), _C.ptr(grad_invdepth), _C.ptr(scratch),
-                                          scratch.numel(), C.byref(gr), _stream()))
+                try:
+                    _C.check(lib.gsr_backward(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom), _C.ptr(binning),
+                                              _C.ptr(img), R, _C.ptr(grad_color), _C.ptr(grad_invdepth),
+                                              _C.ptr(scratch), scratch.numel(), C.byref(gr), _stream()))
+                except _C.GsrError:
+                    if rs.debug:
+                        _dump("snapshot_bw.dump", rs, means3D, dc, sh, colors_precomp, opacities, scales, rotations,
+                              cov3D_precomp, grad_color, grad_invdepth, radii)
+                    raise
         return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None)
 
 
