@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views per rank per optimizer step (gradient accumulation; default 1 = the reference's batch-1 step). "
                          "Amortises the N>1 gradient exchange and Adam over k views; value still counts view-iterations")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: exchange all gradients on the main stream (default overlaps the SH exchange + Adam with the next "
+                         "step's geometry stages; same results, DESIGN.md 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
@@ -216,7 +219,8 @@ def main():
     model, cams, gts, depth_gts, my_views, pipe, bg, cfg, render = build_scene(args, device, rank, world)
     trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=args.optimizer,
                       loss=args.loss, separate_sh=not args.concat_sh, depth_targets=depth_gts,
-                      depth_weight=1.0 if depth_gts is not None else 0.0)
+                      depth_weight=1.0 if depth_gts is not None else 0.0,
+                      overlap_comm=False if args.no_overlap else None)
     if args.densify:
         # cameras_extent of the reference = 1.1 x radius of the camera centres (scene/dataset_readers.py getNerfppNorm)
         trainer.enable_densification(extent=1.1 * 4.0, from_iter=args.densify_from)
@@ -264,7 +268,7 @@ def main():
                    "gaussians": P, "gaussians_final": int(model.get_xyz.shape[0]), "densify": bool(args.densify),
                    "sh_degree": cfg["deg"], "width": W, "height": H, "views": len(cams),
                    "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}",
-                   "views_per_rank_per_step": k,
+                   "views_per_rank_per_step": k, "overlap_comm": bool(trainer.overlap_comm),
                    "loss": "L1 + 0.2 DSSIM (" + ("HIP fused SSIM" if args.loss == "hip" else "torch conv2d SSIM") + ")",
                    "optimizer": {"hip": "Adam, one-launch HIP kernel (torch.optim.Adam semantics)",
                                  "hip_sparse": "SparseGaussianAdam (HIP)", "torch": "torch.optim.Adam"}[args.optimizer]},

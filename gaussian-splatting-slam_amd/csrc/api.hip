@@ -12,8 +12,9 @@
 #include "gsr_common.h"
 
 // launchers defined in the kernel files
-void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&,
+void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool,
                                hipStream_t);
+void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, hipStream_t);
 void gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
                                const GsrGeomLayout&, const float4*, const gsr_grads*, hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
@@ -187,8 +188,8 @@ size_t gsr_backward_scratch_bytes(int32_t P, int64_t R) {
   return gsr_align((size_t)(R < 1 ? 1 : R) * 16 * GSR_IGRAD_F4);
 }
 
-int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
-                            size_t geometry_bytes, int32_t* radii, void* stream) {
+static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
+                                    size_t geometry_bytes, int32_t* radii, void* stream, bool defer_color) {
   int rc = validate(s, g);
   if (rc) return rc;
   const int P = g->P;
@@ -203,7 +204,7 @@ int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void*
   uint32_t* meta = (uint32_t*)(geom + L.meta);
   if ((rc = gsr_check(hipMemsetAsync(meta, 0, 64, st), "memset meta"))) return rc;
 
-  gsr_launch_preprocess_fwd(s, g, radii, geom, L, st);
+  gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
 
   // depth order of the Gaussians (stable, so equal depths keep ascending id); 4 passes -> result in (depth_key, order)
@@ -234,6 +235,26 @@ int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void*
     return GSR_ERR_TOO_MANY_INSTANCES;
   }
   return (int64_t)host[0];
+}
+
+int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
+                            size_t geometry_bytes, int32_t* radii, void* stream) {
+  return forward_prepare_impl(s, g, geometry_state, geometry_bytes, radii, stream, false);
+}
+
+int64_t gsr_forward_prepare_geometry(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
+                                     size_t geometry_bytes, int32_t* radii, void* stream) {
+  return forward_prepare_impl(s, g, geometry_state, geometry_bytes, radii, stream, true);
+}
+
+int gsr_forward_shade(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* stream) {
+  int rc = validate(s, g);
+  if (rc) return rc;
+  if (g->P == 0) return 0;
+  const GsrGeomLayout L = gsr_geom_layout(g->P);
+  gsr_launch_shade(s, g, (char*)geometry_state, L, (hipStream_t)stream);
+  if ((rc = debug_sync(s, (hipStream_t)stream, "shade"))) return rc;
+  return gsr_check(hipGetLastError(), "shade launch");
 }
 
 int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     float scale_modifier, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy, int prefiltered, int antialiasing,
-    int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
+    int defer_color, int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
     uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
@@ -267,6 +267,8 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
           rgb[0] = colors_precomp[3 * (size_t)idx];
           rgb[1] = colors_precomp[3 * (size_t)idx + 1];
           rgb[2] = colors_precomp[3 * (size_t)idx + 2];
+        } else if (defer_color) {
+          rgb[0] = rgb[1] = rgb[2] = 0.f;   // k_shade fills the colour (and `clamped`) right before compositing
         } else {
           float dx = p[0] - v.cam[0], dy = p[1] - v.cam[1], dz = p[2] - v.cam[2];
           const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -338,6 +340,55 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
   radii[idx] = out_radius;
   tiles_touched[idx] = out_tiles;
   depth_key[idx] = out_key;   // `order` is not written: the depth sort takes value = index on its first pass
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Deferred colour pass (SH -> RGB of K1 as its own kernel).  Used by the view-sharded data-parallel trainer: the SH
+// coefficients are 81 % of the gradient bytes, and with the colour evaluated HERE - after projection, depth sort, emission and
+// tile sort - their all-reduce + Adam update can still be in flight on another stream while those geometry stages of the
+// next step run.  Same arithmetic as the fused K1 path (bitwise identical colours).
+// ---------------------------------------------------------------------------------------------------
+template <bool STAGE>
+__global__ __launch_bounds__(256) void k_shade(int P, int deg, int sh_stride, const float* __restrict__ means3D,
+                                               const float* __restrict__ dc, const float* __restrict__ shs,
+                                               const float* __restrict__ campos,
+                                               const uint32_t* __restrict__ tiles_touched, float4* __restrict__ rec,
+                                               uint8_t* __restrict__ clamped) {
+  extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int S = 3 * sh_stride, Sp = S | 1;
+  if (STAGE) {
+    const size_t row0 = (size_t)blockIdx.x * 256;
+    const int rows = (int)min((size_t)256, (size_t)P - row0);
+    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds);
+    __syncthreads();
+  }
+  if (idx >= P || tiles_touched[idx] == 0) return;
+  const float* my_row = sh_lds + threadIdx.x * Sp;
+  float dx = means3D[3 * (size_t)idx] - campos[0], dy = means3D[3 * (size_t)idx + 1] - campos[1],
+        dz = means3D[3 * (size_t)idx + 2] - campos[2];
+  const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  dx *= inv; dy *= inv; dz *= inv;
+  float bs[16];
+  sh_basis_eval(deg, dx, dy, dz, bs);
+  const int K = (deg + 1) * (deg + 1);
+  float rgb[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < K; k++) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+      rgb[ch] += bs[k] * (STAGE ? sh_coef_lds(dc, my_row, idx, k, ch) : sh_coef(dc, shs, sh_stride, idx, k, ch));
+  }
+  uint8_t cl = 0;
+#pragma unroll
+  for (int ch = 0; ch < 3; ch++) {
+    rgb[ch] += 0.5f;
+    if (rgb[ch] < 0.f) { cl |= (1u << ch); rgb[ch] = 0.f; }
+  }
+  float* r = reinterpret_cast<float*>(rec + 3 * (size_t)idx);
+  r[7] = rgb[0];      // r1.w
+  r[8] = rgb[1];      // r2.x
+  r[9] = rgb[2];      // r2.y
+  clamped[idx] = cl;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -679,15 +730,30 @@ static bool can_stage_sh(const gsr_settings* s, const gsr_gaussians* g, size_t* 
   return true;
 }
 
-void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, int32_t* radii, char* geom,
-                               const GsrGeomLayout& L, hipStream_t st) {
+void gsr_launch_shade(const gsr_settings* s, const gsr_gaussians* g, char* geom, const GsrGeomLayout& L, hipStream_t st) {
   const int P = g->P;
+  if (P == 0 || g->colors_precomp) return;
   size_t lds = 0;
   const bool stage = can_stage_sh(s, g, &lds);
+#define GSR_SHADE_ARGS                                                                                           \
+  P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, s->campos, (const uint32_t*)(geom + L.tiles_touched), \
+      (float4*)(geom + L.rec), (uint8_t*)(geom + L.clamped)
+  if (stage)
+    GSR_LAUNCH("shade", k_shade<true>, dim3((P + 255) / 256), dim3(256), lds, st, GSR_SHADE_ARGS);
+  else
+    GSR_LAUNCH("shade", k_shade<false>, dim3((P + 255) / 256), dim3(256), 0, st, GSR_SHADE_ARGS);
+#undef GSR_SHADE_ARGS
+}
+
+void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, int32_t* radii, char* geom,
+                               const GsrGeomLayout& L, bool defer_color, hipStream_t st) {
+  const int P = g->P;
+  size_t lds = 0;
+  const bool stage = !defer_color && can_stage_sh(s, g, &lds);
 #define GSR_PRE_FWD_ARGS                                                                                              \
   P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations, \
       g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width, s->image_height,  \
-      s->tanfovx, s->tanfovy, s->prefiltered, s->antialiasing, radii, (float4*)(geom + L.rec),                        \
+      s->tanfovx, s->tanfovy, s->prefiltered, s->antialiasing, (int)defer_color, radii, (float4*)(geom + L.rec),     \
       (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles_touched),              \
       (ushort4*)(geom + L.rect), (uint8_t*)(geom + L.clamped), (uint32_t*)(geom + L.meta)
   if (stage)

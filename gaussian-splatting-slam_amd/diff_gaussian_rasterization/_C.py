@@ -54,6 +54,9 @@ EXPORTS = {
     "gsr_backward_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "gsr_forward_prepare": (C.c_int64, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_void_p]),
+    "gsr_forward_prepare_geometry": (C.c_int64, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p,
+                                                 C.c_size_t, C.c_void_p, C.c_void_p]),
+    "gsr_forward_shade": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p]),
     "gsr_forward_render": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p]),

@@ -36,6 +36,18 @@ class GaussianRasterizationSettings(NamedTuple):
     antialiasing: bool = False
 
 
+# One-shot hand-off used by the view-sharded data-parallel trainer (scene_utils/trainer.py): when set, the NEXT forward runs
+# the geometry stages first, makes the current stream wait for this event (the SH coefficients' all-reduce + Adam update,
+# in flight on another stream), and only then evaluates the colours (gsr_forward_prepare_geometry / gsr_forward_shade).
+_sh_ready_event = None
+
+
+def defer_sh_until(event):
+    """`event`: a recorded torch.cuda.Event after which `dc` / `shs` hold this step's values (None cancels)."""
+    global _sh_ready_event
+    _sh_ready_event = event
+
+
 # statistics of the most recent forward call (bench.py reports the measured num_rendered with every number)
 last_call_stats = {"num_rendered": 0}
 
@@ -110,9 +122,19 @@ class _RasterizeGaussians(torch.autograd.Function):
             g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
             geom = torch.empty(lib.gsr_geometry_state_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(lib.gsr_image_state_bytes(W, H), dtype=torch.uint8, device=dev)
+            global _sh_ready_event
+            ev, _sh_ready_event = _sh_ready_event, None
             try:
-                R = _C.check(lib.gsr_forward_prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
-                                                     _stream()))
+                if ev is not None and colors_precomp is None:
+                    R = _C.check(lib.gsr_forward_prepare_geometry(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(),
+                                                                  _C.ptr(radii), _stream()))
+                    torch.cuda.current_stream().wait_event(ev)     # SH coefficients of this step are final after this
+                    _C.check(lib.gsr_forward_shade(C.byref(s), C.byref(g), _C.ptr(geom), _stream()))
+                else:
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                    R = _C.check(lib.gsr_forward_prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(),
+                                                         _C.ptr(radii), _stream()))
                 binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
                 _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning), binning.numel(),
                                                 R, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invdepth),

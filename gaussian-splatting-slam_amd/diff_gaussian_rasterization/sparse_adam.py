@@ -23,9 +23,22 @@ def _arrays(tensors_p, tensors_g, tensors_m, tensors_v, lrs):
 
 
 class _GsrAdamBase(torch.optim.Adam):
-    def _collect(self):
+    def init_state(self):
+        """Create the moments of every parameter now (on the current stream) instead of lazily at the first step."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    def _collect(self, only=None):
+        """`only`: optional collection of group names; other groups are left untouched this call."""
         ps, gs, ms, vs, lrs, states = [], [], [], [], [], []
         for group in self.param_groups:
+            if only is not None and group.get("name") not in only:
+                continue
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -46,8 +59,8 @@ class FusedAdam(_GsrAdamBase):
         super().__init__(params=params, lr=lr, betas=betas, eps=eps)
 
     @torch.no_grad()
-    def step(self):
-        ps, gs, ms, vs, lrs, states = self._collect()
+    def step(self, only=None):
+        ps, gs, ms, vs, lrs, states = self._collect(only)
         if not ps:
             return
         g0 = self.param_groups[0]
@@ -69,8 +82,8 @@ class SparseGaussianAdam(_GsrAdamBase):
         super().__init__(params=params, lr=lr, eps=eps)
 
     @torch.no_grad()
-    def step(self, visibility, N):
-        ps, gs, ms, vs, lrs, states = self._collect()
+    def step(self, visibility, N, only=None):
+        ps, gs, ms, vs, lrs, states = self._collect(only)
         if not ps:
             return
         vis = visibility.to(torch.uint8).contiguous()

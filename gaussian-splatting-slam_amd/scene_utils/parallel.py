@@ -49,13 +49,15 @@ class GradBucket:
     def __init__(self, params):
         self.params = list(params)
 
-    def all_reduce_mean(self, world: int, group=None):
+    def all_reduce_mean(self, world: int, group=None, params=None):
+        """`params`: optional subset of the bucket's parameters to exchange in this call."""
         if world <= 1:
             return
         backend = dist.get_backend(group)
         use_avg = backend == "nccl"                  # RCCL averages in the reduction; gloo has no AVG
+        todo = self.params if params is None else list(params)
         works = []
-        for p in self.params:
+        for p in todo:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             g = p.grad
@@ -66,7 +68,7 @@ class GradBucket:
         for w in works:
             w.wait()
         if not use_avg:
-            for p in self.params:
+            for p in todo:
                 p.grad.mul_(1.0 / world)
 
 

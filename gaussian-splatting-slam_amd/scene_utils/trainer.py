@@ -11,7 +11,7 @@ from .parallel import GradBucket, reduce_densification_stats
 
 class Trainer:
     def __init__(self, model, cameras, gt_images, render_fn, pipe, bg, lambda_dssim=0.2, world=1, rank=0,
-                 optimizer="hip", loss="hip", depth_targets=None, depth_weight=0.0, separate_sh=False):
+                 optimizer="hip", loss="hip", depth_targets=None, depth_weight=0.0, separate_sh=False, overlap_comm=None):
         """optimizer: "hip" (one-launch HIP Adam, default-optimizer semantics), "hip_sparse" (SparseGaussianAdam, the
         reference's accelerated choice) or "torch" (torch.optim.Adam; CPU tests).  loss: "hip" (fused SSIM kernels) or
         "torch" (pure-PyTorch ssim; CPU tests)."""
@@ -27,6 +27,14 @@ class Trainer:
         self.depth_targets, self.depth_weight = depth_targets, depth_weight
         # reference train.py:106 passes separate_sh=SPARSE_ADAM_AVAILABLE: dc / rest go to the rasterizer unconcatenated
         self.separate_sh = separate_sh
+        # Overlap of the cross-rank exchange with the next step's geometry stages: needs the HIP device, the
+        # HIP optimizers (they step parameter groups separately) and dc / rest passed unconcatenated (separate_sh), because a
+        # torch.cat of the SH tensors would read them on the main stream while their update is still in flight.
+        can_overlap = world > 1 and optimizer in ("hip", "hip_sparse") and separate_sh and model.get_xyz.is_cuda
+        self.overlap_comm = can_overlap if overlap_comm is None else (bool(overlap_comm) and can_overlap)
+        self.side_stream = torch.cuda.Stream(device=model.get_xyz.device) if self.overlap_comm else None
+        if self.overlap_comm:
+            self.optimizer.init_state()      # moments live in the main stream's pool, never the side stream's
         self.densify = None          # schedule dict once enable_densification() is called
         self.iteration = 0
         self.last = {}
@@ -73,6 +81,17 @@ class Trainer:
             vis = vis_any | vis
         self.iteration += 1
         self.last = dict(loss=loss.detach(), image=image.detach(), radii=radii)
+        if self.world > 1 and self.optimizer_kind == "hip_sparse":
+            # SparseGaussianAdam updates the rows visible in "the" view; with views sharded over ranks that is the UNION of
+            # the ranks' visibility masks (a Gaussian seen by any rank has a non-zero averaged gradient) - otherwise the
+            # replicas would drift apart
+            import torch.distributed as dist
+            v8 = vis.to(torch.uint8)
+            dist.all_reduce(v8, op=dist.ReduceOp.MAX)
+            vis = v8.bool()
+        if self.overlap_comm and not self._densify_due():
+            self._exchange_and_step_overlapped(vis, radii)
+            return self.last
         with torch.no_grad():
             if self.bucket is not None:
                 self.bucket.all_reduce_mean(self.world)
@@ -86,6 +105,51 @@ class Trainer:
                 self.optimizer.step()
             self.optimizer.zero_grad(set_to_none=True)
         return self.last
+
+    def _densify_due(self):
+        d, it = self.densify, self.iteration
+        if d is None or it >= d["until_iter"]:
+            return False
+        return (it > d["from_iter"] and it % d["interval"] == 0) or it % d["reset"] == 0
+
+    @torch.no_grad()
+    def _exchange_and_step_overlapped(self, vis, radii):
+        """Synchronous data parallelism, same result as the plain path, different schedule: the SH gradients (f_dc, f_rest:
+        48 of the 59 floats per Gaussian) are all-reduced and applied on a side stream; the main stream exchanges and applies
+        the geometry gradients (11 floats) and goes straight on to the next step, whose rasterizer runs projection, depth
+        sort, emission and tile sort before it waits for the SH update (diff_gaussian_rasterization.defer_sh_until)."""
+        import diff_gaussian_rasterization as dgr
+        m = self.model
+        geo, geo_names = [m._xyz, m._opacity, m._scaling, m._rotation], ("xyz", "opacity", "scaling", "rotation")
+        sh, sh_names = [m._features_dc, m._features_rest], ("f_dc", "f_rest")
+        main, side = torch.cuda.current_stream(), self.side_stream
+        side.wait_stream(main)                                   # gradients are complete on the main stream
+        with torch.cuda.stream(side):
+            for p in sh:
+                if p.grad is not None:
+                    p.grad.record_stream(side)
+            vis.record_stream(side)
+            self.bucket.all_reduce_mean(self.world, params=sh)
+            if self.optimizer_kind == "hip_sparse":
+                self.optimizer.step(vis, radii.shape[0], only=sh_names)
+            else:
+                self.optimizer.step(only=sh_names)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.bucket.all_reduce_mean(self.world, params=geo)
+        if self.optimizer_kind == "hip_sparse":
+            self.optimizer.step(vis, radii.shape[0], only=geo_names)
+        else:
+            self.optimizer.step(only=geo_names)
+        dgr.defer_sh_until(ev)                                   # consumed by the next rasterizer forward
+        self._pending_sh_event = ev
+        self.optimizer.zero_grad(set_to_none=True)
+
+    def finish(self):
+        """Make the main stream wait for an SH update still in flight (call before reading the parameters outside step())."""
+        ev = getattr(self, "_pending_sh_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def _maybe_densify(self, radii):
         d, it = self.densify, self.iteration

@@ -106,6 +106,15 @@ size_t gsr_backward_scratch_bytes(int32_t P, int64_t num_rendered);
 int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
                             size_t geometry_bytes, int32_t* radii, void* stream);
 
+/* Split form of phase 1 for the view-sharded data-parallel trainer: gsr_forward_prepare_geometry does everything
+ * gsr_forward_prepare does EXCEPT the SH -> RGB evaluation (it does not read `dc` / `shs`); gsr_forward_shade fills the colours
+ * and must run before gsr_forward_render.  Between the two calls the caller may wait for the SH coefficients of this step
+ * (81 % of the gradient bytes) to finish their all-reduce + Adam update on another stream.  Results are bitwise identical
+ * to the fused gsr_forward_prepare. */
+int64_t gsr_forward_prepare_geometry(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
+                                     size_t geometry_bytes, int32_t* radii, void* stream);
+int gsr_forward_shade(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* stream);
+
 /* Forward, phase 2: instance emission, tile sort, tile ranges and 16x16-tile alpha compositing.
  * Writes out_color[3,H,W] and out_invdepth[1,H,W] (reference :90,:101 `rendered_image`, `depth_image`).
  * `for_backward` != 0 additionally records what gsr_backward needs in the state buffers. */

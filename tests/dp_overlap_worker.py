@@ -1,0 +1,60 @@
+"""Worker for tests/test_dp_overlap_gpu.py: launched with torch.distributed.run, 2 ranks sharing ONE GPU, gloo between them.
+Trains the same scene twice - plain synchronous exchange, then the overlapped schedule - and checks the parameters are identical
+on both ranks and between the two schedules."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+os.environ["BENCH_SHARE_GPU"] = "1"
+from scene_utils import init_from_env, shard_views, Trainer, GaussianModel, make_gaussians, fibonacci_cameras  # noqa: E402
+from gaussian_renderer import render, PipelineParams  # noqa: E402
+
+
+def run(overlap, optimizer, rank, world, steps=6):
+    dev = "cuda:0"
+    raw = make_gaussians(3000, 2, seed=12, scale_factor=0.8)
+    cams = fibonacci_cameras(4, 128, 80, seed=13, device=dev)
+    teacher = GaussianModel.from_raw(make_gaussians(3000, 2, seed=14, scale_factor=0.8).to(dev), requires_grad=False)
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams()
+    with torch.no_grad():
+        gts = {i: render(c, teacher, pipe, bg)["render"].clone() for i, c in enumerate(cams)}
+    model = GaussianModel.from_raw(raw.to(dev))
+    tr = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=optimizer, separate_sh=True,
+                 overlap_comm=overlap)
+    assert tr.overlap_comm == overlap
+    tr.enable_densification(extent=4.4, from_iter=2, until_iter=100, interval=4, opacity_reset_interval=50, grad_threshold=2e-5)
+    mine = shard_views(len(cams), rank, world)
+    for it in range(steps):
+        tr.step(mine[it % len(mine)])
+    tr.finish()
+    torch.cuda.synchronize()
+    return [p.detach().clone() for p in model.parameters()]
+
+
+def main():
+    rank, world, _ = init_from_env("gloo")
+    torch.cuda.set_device(0)
+    for optimizer in ("hip", "hip_sparse"):
+        plain = run(False, optimizer, rank, world)
+        over = run(True, optimizer, rank, world)
+        for a, b in zip(plain, over):
+            assert a.shape == b.shape and torch.equal(a, b), f"overlapped schedule changed the result ({optimizer})"
+        # both ranks hold the same parameters
+        for t in over:
+            other = t.clone()
+            dist.broadcast(other, src=0)
+            assert torch.equal(other, t), f"ranks diverged ({optimizer})"
+    if rank == 0:
+        print("DP_OVERLAP_OK")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -387,3 +387,21 @@ def test_low_level_C_call_forms():
     assert torch.equal(d_op.cpu(), ref["grads"]["opacities"]) and torch.equal(d_sc.cpu(), ref["grads"]["scales"])
     vis = _C.mark_visible(inp["means3D"], cam.world_view_transform.cuda(), cam.full_proj_transform.cuda())
     assert vis.dtype == torch.bool and int(vis.sum()) >= int((radii > 0).sum())
+
+
+@pytest.mark.parametrize("mode", ["sh", "dc"])
+def test_deferred_colour_path_is_bit_identical(mode):
+    """gsr_forward_prepare_geometry + gsr_forward_shade (used under the data-parallel overlap) against the fused K1 path."""
+    import diff_gaussian_rasterization as dgr
+    raw, cam = small_scene(P=2500)
+    bg = torch.tensor([0.2, 0.1, 0.4])
+    gc, gd = upstream_grads(cam.image_height, cam.image_width)
+    a = run_hip(raw, cam, 3, bg, mode=mode, gc=gc, gd=gd)
+    ev = torch.cuda.Event()
+    ev.record()
+    dgr.defer_sh_until(ev)
+    b = run_hip(raw, cam, 3, bg, mode=mode, gc=gc, gd=gd)
+    assert dgr._sh_ready_event is None                       # one-shot: consumed by the forward
+    assert torch.equal(a["color"], b["color"]) and torch.equal(a["invdepth"], b["invdepth"]) and torch.equal(a["radii"], b["radii"])
+    for k in a["grads"]:
+        assert torch.equal(a["grads"][k], b["grads"][k]), k
