@@ -123,7 +123,10 @@ class Trainer:
         geo, geo_names = [m._xyz, m._opacity, m._scaling, m._rotation], ("xyz", "opacity", "scaling", "rotation")
         sh, sh_names = [m._features_dc, m._features_rest], ("f_dc", "f_rest")
         main, side = torch.cuda.current_stream(), self.side_stream
-        side.wait_stream(main)                                   # gradients are complete on the main stream
+        # Collectives of one communicator run in ISSUE order (RCCL keeps one internal stream per communicator): the small
+        # geometry exchange goes first so that the main stream only ever waits for it; the SH exchange queues behind it.
+        self.bucket.all_reduce_mean(self.world, params=geo)
+        side.wait_stream(main)                                   # gradients complete (and the geometry exchange issued)
         with torch.cuda.stream(side):
             for p in sh:
                 if p.grad is not None:
@@ -136,7 +139,6 @@ class Trainer:
                 self.optimizer.step(only=sh_names)
             ev = torch.cuda.Event()
             ev.record(side)
-        self.bucket.all_reduce_mean(self.world, params=geo)
         if self.optimizer_kind == "hip_sparse":
             self.optimizer.step(vis, radii.shape[0], only=geo_names)
         else:
