@@ -10,7 +10,11 @@
 // an id-ordered input).
 #include "gsr_common.h"
 
-// one thread per depth-sorted position j
+// One thread per depth-sorted position j.  The 256 Gaussians of a workgroup are consecutive in depth order, so their
+// emission slots form ONE contiguous range [slot0, slot0 + count): the (tile, Gaussian) pairs are assembled in LDS and then
+// written with coalesced stores (per-thread 4-B stores at scattered addresses ran at ~0.5 TB/s).  Ranges that do not fit
+// the LDS window (a few huge splats) are written directly.
+#define EMIT_WINDOW 4096
 __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ offsets_incl,
                                                         const uint32_t* __restrict__ tiles_touched,
@@ -18,32 +22,50 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
                                                         const float4* __restrict__ rec, uint32_t* __restrict__ tile_key,
                                                         uint32_t* __restrict__ gauss_of_slot,
                                                         uint32_t* __restrict__ slot_start) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= P) return;
-  const uint32_t g = order[j];
-  const uint32_t n = tiles_touched[g];
-  if (n == 0) return;  // culled Gaussians sort to the end (key 0xFFFFFFFF) and emit nothing
-  uint32_t off = offsets_incl[j] - n;
-  slot_start[g] = off;
-  const ushort4 r = rect[g];
-  // same inputs (the stored record) and the same compiled row-interval routine as k_preprocess_fwd -> exactly n tiles
-  const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1];
-  const float q = -2.0f * r1.z;
-  const uint32_t end = off + n;
-  for (int y = r.y; y < r.w; y++) {
-    const uint32_t iv = gsr_row_interval(r0.x, r0.y, r0.z, r0.w, r1.x, q, y, r.x, r.z);
-    const int lo = (int)(iv & 0xFFFFu), hi = (int)(iv >> 16);
-    for (int x = lo; x < hi && off < end; x++) {
-      tile_key[off] = (uint32_t)(y * grid_x + x);
-      gauss_of_slot[off] = g;
-      off++;
+  __shared__ uint32_t lkey[EMIT_WINDOW], lgid[EMIT_WINDOW];
+  const int j0 = blockIdx.x * 256;
+  const int j = j0 + threadIdx.x;
+  const int jlast = min(j0 + 255, P - 1);
+  const uint32_t slot0 = (j0 == 0) ? 0u : offsets_incl[j0 - 1];
+  const uint32_t count = offsets_incl[jlast] - slot0;            // block-uniform
+  const bool staged = count <= EMIT_WINDOW;
+  if (j < P) {
+    const uint32_t g = order[j];
+    const uint32_t n = tiles_touched[g];
+    if (n != 0) {  // culled Gaussians sort to the end (key 0xFFFFFFFF) and emit nothing
+      uint32_t off = offsets_incl[j] - n;
+      slot_start[g] = off;
+      const ushort4 r = rect[g];
+      // same inputs (the stored record) and the same compiled row-interval routine as k_preprocess_fwd -> exactly n tiles
+      const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1];
+      const float q = -2.0f * r1.z;
+      const uint32_t end = off + n;
+      uint32_t* kdst = staged ? lkey : tile_key;
+      uint32_t* gdst = staged ? lgid : gauss_of_slot;
+      const uint32_t bias = staged ? slot0 : 0u;
+      for (int y = r.y; y < r.w; y++) {
+        const uint32_t iv = gsr_row_interval(r0.x, r0.y, r0.z, r0.w, r1.x, q, y, r.x, r.z);
+        const int lo = (int)(iv & 0xFFFFu), hi = (int)(iv >> 16);
+        for (int x = lo; x < hi && off < end; x++) {
+          kdst[off - bias] = (uint32_t)(y * grid_x + x);
+          gdst[off - bias] = g;
+          off++;
+        }
+      }
+      // belt and braces: if fewer tiles passed than were counted (cannot happen with one compiled test body), park the
+      // unused slots on this Gaussian's first tile with a sentinel Gaussian id that the render kernels treat as empty
+      for (; off < end; off++) {
+        kdst[off - bias] = (uint32_t)(r.y * grid_x + r.x);
+        gdst[off - bias] = 0xFFFFFFFFu;
+      }
     }
   }
-  // belt and braces: if fewer tiles passed than were counted (cannot happen with one compiled test body), park the unused
-  // slots on this Gaussian's first tile with a sentinel Gaussian id that the render kernels treat as empty
-  for (; off < end; off++) {
-    tile_key[off] = (uint32_t)(r.y * grid_x + r.x);
-    gauss_of_slot[off] = 0xFFFFFFFFu;
+  if (staged) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < count; i += 256) {
+      tile_key[slot0 + i] = lkey[i];
+      gauss_of_slot[slot0 + i] = lgid[i];
+    }
   }
 }
 
