@@ -30,8 +30,10 @@ class Trainer:
         # Overlap of the cross-rank exchange with the next step's geometry stages: needs the HIP device, the
         # HIP optimizers (they step parameter groups separately) and dc / rest passed unconcatenated (separate_sh), because a
         # torch.cat of the SH tensors would read them on the main stream while their update is still in flight.
-        can_overlap = world > 1 and optimizer in ("hip", "hip_sparse") and separate_sh and model.get_xyz.is_cuda
-        self.overlap_comm = can_overlap if overlap_comm is None else (bool(overlap_comm) and can_overlap)
+        can_overlap = optimizer in ("hip", "hip_sparse") and separate_sh and model.get_xyz.is_cuda
+        # default: on for N > 1.  On one GPU it can be requested, but it buys nothing (measured 2.22 vs 2.21 ms/step at C3: the
+        # Adam kernel fills the machine, the small geometry kernels just queue behind it); what it hides is COMMUNICATION.
+        self.overlap_comm = (can_overlap and world > 1) if overlap_comm is None else (bool(overlap_comm) and can_overlap)
         self.side_stream = torch.cuda.Stream(device=model.get_xyz.device) if self.overlap_comm else None
         if self.overlap_comm:
             self.optimizer.init_state()      # moments live in the main stream's pool, never the side stream's
@@ -125,14 +127,16 @@ class Trainer:
         main, side = torch.cuda.current_stream(), self.side_stream
         # Collectives of one communicator run in ISSUE order (RCCL keeps one internal stream per communicator): the small
         # geometry exchange goes first so that the main stream only ever waits for it; the SH exchange queues behind it.
-        self.bucket.all_reduce_mean(self.world, params=geo)
+        if self.bucket is not None:
+            self.bucket.all_reduce_mean(self.world, params=geo)
         side.wait_stream(main)                                   # gradients complete (and the geometry exchange issued)
         with torch.cuda.stream(side):
             for p in sh:
                 if p.grad is not None:
                     p.grad.record_stream(side)
             vis.record_stream(side)
-            self.bucket.all_reduce_mean(self.world, params=sh)
+            if self.bucket is not None:
+                self.bucket.all_reduce_mean(self.world, params=sh)
             if self.optimizer_kind == "hip_sparse":
                 self.optimizer.step(vis, radii.shape[0], only=sh_names)
             else:
