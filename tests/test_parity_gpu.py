@@ -405,3 +405,59 @@ def test_deferred_colour_path_is_bit_identical(mode):
     assert torch.equal(a["color"], b["color"]) and torch.equal(a["invdepth"], b["invdepth"]) and torch.equal(a["radii"], b["radii"])
     for k in a["grads"]:
         assert torch.equal(a["grads"][k], b["grads"][k]), k
+
+
+def test_autograd_usage_patterns():
+    """Two renders in one graph, retain_graph double backward, partial requires_grad, non-contiguous SH input."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    raw = make_gaussians(2000, 3, seed=71, scale_factor=0.7)
+    cams = fibonacci_cameras(3, 112, 80, seed=72)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    dev = "cuda"
+    inp = leaf_inputs(raw, torch.float32, dev)
+    rs = [settings_for(c, 3, bg, cls=GaussianRasterizationSettings, device=dev) for c in cams[:2]]
+
+    def call(s, shs=None, **over):
+        kw = dict(means3D=inp["means3D"], means2D=inp["means2D"], opacities=inp["opacities"], shs=inp["shs"] if shs is None else shs,
+                  scales=inp["scales"], rotations=inp["rotations"])
+        kw.update(over)
+        return GaussianRasterizer(s)(**kw)
+
+    # (1) two views in one graph: gradients add up
+    c0, _, _ = call(rs[0])
+    c1, _, _ = call(rs[1])
+    (c0.sum() + 2.0 * c1.sum()).backward()
+    both = {k: v.grad.clone() for k, v in inp.items()}
+    for v in inp.values():
+        v.grad = None
+    call(rs[0])[0].sum().backward()
+    g0 = {k: v.grad.clone() for k, v in inp.items()}
+    for v in inp.values():
+        v.grad = None
+    (2.0 * call(rs[1])[0].sum()).backward()
+    for k, v in inp.items():
+        assert rel_l2((g0[k] + v.grad).cpu(), both[k].cpu()) < 1e-6, k
+        v.grad = None
+    # (2) retain_graph: the saved state survives a first backward
+    c0, _, d0 = call(rs[0])
+    loss = c0.sum() + d0.sum()
+    loss.backward(retain_graph=True)
+    first = inp["means3D"].grad.clone()
+    inp["means3D"].grad = None
+    loss.backward()
+    assert torch.equal(first, inp["means3D"].grad)
+    for v in inp.values():
+        v.grad = None
+    # (3) only some inputs require grad
+    frozen = inp["shs"].detach()
+    c0, _, _ = call(rs[0], shs=frozen)
+    c0.sum().backward()
+    assert inp["means3D"].grad is not None and frozen.grad is None
+    assert rel_l2(inp["means3D"].grad.cpu(), g0["means3D"].cpu()) < 1e-6
+    for v in inp.values():
+        v.grad = None
+    # (4) non-contiguous SH tensor (a transposed view, as the reference builds for its python SH path)
+    sh_t = inp["shs"].detach().transpose(1, 2).contiguous().requires_grad_(True)          # [P,3,16]
+    c0, _, _ = call(rs[0], shs=sh_t.transpose(1, 2))
+    c0.sum().backward()
+    assert rel_l2(sh_t.grad.transpose(1, 2).cpu(), g0["shs"].cpu()) < 1e-6
