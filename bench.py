@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--views", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
-    ap.add_argument("--cpu-tiles", type=int, default=64)
+    ap.add_argument("--cpu-tiles", type=int, default=256)
     ap.add_argument("--optimizer", default="hip", choices=["hip", "hip_sparse", "torch"])
     ap.add_argument("--loss", default="hip", choices=["hip", "torch"])
     ap.add_argument("--concat-sh", action="store_true",
