@@ -394,8 +394,10 @@ __global__ __launch_bounds__(256) void k_shade(int P, int deg, int sh_stride, co
 // ---------------------------------------------------------------------------------------------------
 // K8 + K9 backward, fused with the per-Gaussian gather of per-instance gradients.
 // One thread per Gaussian index (all per-Gaussian arrays coalesced).
-// igrad record (render backward): (d_mx_ndc, d_my_ndc, dA, dB) (dC, d_opacity_eff, d_r, d_g) (d_b, d_invdepth, -, -)
-// where dB is the true derivative wrt conic.B (power = -0.5(A dx^2 + C dy^2) - B dx dy).
+// igrad record (render backward): (S_x, S_y, S_xx, S_xy) (S_yy, d_opacity_eff, d_r, d_g) (d_b, d_invdepth, -, -) with
+// S_* = sums over the instance's pixels of g, g dx, ... (g = dL/dpower, d = mean - pixel).  With
+// power = -0.5(A dx^2 + C dy^2) - B dx dy:  dL/dA = -S_xx/2, dL/dB = -S_xy, dL/dC = -S_yy/2 and
+// dL/dmean2D(ndc) = (W/2)(-A S_x - B S_y), (H/2)(-C S_y - B S_x): linear in the sums, so applied once, after the gather.
 // ---------------------------------------------------------------------------------------------------
 template <bool STAGE>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
@@ -460,9 +462,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
       acc[8] += r2.x; acc[9] += r2.y;
     }
-    g_m2d[0] = acc[0];
-    g_m2d[1] = acc[1];
-    const float gA = acc[2], gB = acc[3], gC = acc[4], g_op_eff = acc[5];
+    const float gA = -0.5f * acc[2], gB = -acc[3], gC = -0.5f * acc[4], g_op_eff = acc[5];
     float g_rgb[3] = {acc[6], acc[7], acc[8]};
     const float g_invd = acc[9];
 
@@ -539,6 +539,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     ewa_project(t, v, cov6, fx, fy, tanfovx, tanfovy, e);
     const float a = e.a0 + 0.3f, c = e.c0 + 0.3f, b = e.b;
     const float det = a * c - b * b;
+    {
+      // conic exactly as the forward computed it (a visible Gaussian has det != 0)
+      const float det_inv = 1.0f / det;
+      const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
+      g_m2d[0] = (0.5f * W) * (-cA * acc[0] - cB * acc[1]);
+      g_m2d[1] = (0.5f * H) * (-cC * acc[1] - cB * acc[0]);
+    }
     const float det2inv = 1.0f / (det * det + 0.0000001f);
     float g_a = det2inv * (-c * c * gA + b * c * gB - b * b * gC);
     float g_c = det2inv * (-b * b * gA + a * b * gB - a * a * gC);

@@ -11,6 +11,9 @@
 // each wave reduces its 64 pixels' contributions with a DPP scan (6 VALU/value), lane 63 adds the wave total
 // into a per-entry LDS accumulator, and the block writes one 48-B gradient record per (tile, instance) with
 // plain coalesced stores.  The per-Gaussian sum over instances happens in k_preprocess_bwd (deterministic).
+// Record = (sum g dx, sum g dy, sum g dx^2, sum g dx dy) (sum g dy^2, dL/dopacity_eff, d_r, d_g) (d_b, d_invdepth, -, -)
+// with g = dL/dpower and d = mean - pixel: raw moments; k_preprocess_bwd turns their per-Gaussian totals into
+// dL/dmean2D and dL/dconic.
 #include "gsr_common.h"
 
 #define ALPHA_MIN (1.0f / 255.0f)
@@ -244,9 +247,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
 
   const int rounds = (toDo + BWD_BATCH - 1) / BWD_BATCH;
   float T = T_final;
-  float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, ad = 0.f;        // colour / invdepth accumulated behind
-  float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f, last_alpha = 0.f;
-  const float halfW = 0.5f * W, halfH = 0.5f * H;
+  // The published per-channel recurrence "colour accumulated behind" ar_c enters the gradient only through
+  // sum_c (c_c - ar_c) gp_c, and the recurrence is linear, so ONE scalar S = sum_c ar_c gp_c (the loss-weighted colour
+  // behind this pixel, depth channel included) carries it:  S <- la * (c_prev . gp) + (1 - la) * S.
+  float S = 0.f, last_cg = 0.f, last_alpha = 0.f;
   float4* myslab = slab[w];
   const bool lane_bit3 = (lane & 8) != 0, octet_lead = (lane & 7) == 0, half_lead = (lane & 31) == 0;
   const int octet_val = (((lane >> 3) & 1) << 2) | ((lane >> 3) & 2) | (((lane >> 3) & 4) >> 2);
@@ -290,25 +294,20 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       const float rcp = __builtin_amdgcn_rcpf(1.0f - a_e);
       T = T * rcp;
       const float dch = a_e * T;
-      ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = bb.w;
-      ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = c.x;
-      ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c.y;
-      if (DEPTH) { ad = last_alpha * ld + (1.f - last_alpha) * ad; ld = c.z; }
+      float cg = bb.w * gp0 + c.x * gp1 + c.y * gp2;                  // this entry's colour . dL/dpixel
+      if (DEPTH) cg += c.z * gd;
+      S = last_alpha * last_cg + (1.f - last_alpha) * S;
+      last_cg = cg;
       last_alpha = a_e;
-      float dL_dalpha = (bb.w - ar0) * gp0 + (c.x - ar1) * gp1 + (c.y - ar2) * gp2;
-      if (DEPTH) dL_dalpha += (c.z - ad) * gd;
-      dL_dalpha = dL_dalpha * T + neg_Tf_bg * rcp;
-      float v6 = dch * gp0, v7 = dch * gp1, v8 = dch * gp2, v9 = DEPTH ? dch * gd : 0.f;
-      const float dL_dG = bb.y * dL_dalpha;
-      const float gdx = G_e * dx, gdy = G_e * dy;
-      const float dG_ddelx = -gdx * a.z - gdy * a.w;
-      const float dG_ddely = -gdy * bb.x - gdx * a.w;
-      float v0 = dL_dG * dG_ddelx * halfW;
-      float v1 = dL_dG * dG_ddely * halfH;
-      float v2 = -0.5f * gdx * dx * dL_dG;
-      float v3 = -gdx * dy * dL_dG;
-      float v4 = -0.5f * gdy * dy * dL_dG;
-      float v5 = G_e * dL_dalpha;
+      const float dL_dalpha = (cg - S) * T + neg_Tf_bg * rcp;
+      const float v6 = dch * gp0, v7 = dch * gp1, v8 = dch * gp2, v9 = DEPTH ? dch * gd : 0.f;
+      // Geometry: only the raw moments of g = dL/dpower = G alpha-gradient are reduced here; the per-Gaussian linear map
+      // to (dL/dmean2D, dL/dconic) uses wave-uniform factors (conic, W/2, H/2) and is applied once per Gaussian AFTER the
+      // sum over its instances, in k_preprocess_bwd.
+      const float v5 = G_e * dL_dalpha;                               // -> dL/dopacity
+      const float g = bb.y * v5;
+      const float v0 = g * dx, v1 = g * dy;                           // sum g dx, sum g dy
+      const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;           // sum g dx^2, g dx dy, g dy^2
       float u0, u1;
       wave_sum10_halving(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, lane_bit3, u0, u1);
       float* dst = reinterpret_cast<float*>(myslab) + 12 * j;
