@@ -38,9 +38,11 @@ __device__ __forceinline__ float swap16_add(float x, float y) {
   const gsr_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
   return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
-template <int CTRL>
+template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_get(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+  // old = 0 + bound_ctrl: lanes without a source (and rows masked off) read 0.0, so `x + dpp_get(x)` folds into ONE
+  // v_add_f32_dpp
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
 
 __device__ __forceinline__ void wave_sum10_halving(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
@@ -66,8 +68,32 @@ __device__ __forceinline__ void wave_sum10_halving(float v0, float v1, float v2,
   u1 = b;
 }
 
-// test hook (tests/test_parity_gpu.py::test_wave_reduction_primitive): in[10][64] -> out[10] through the same store
-// pattern the render backward uses
+// Nine sums (no inverse-depth gradient, the usual training step): v0..v7 by the same halving tree (18 VALU), and the lone
+// ninth value by a plain DPP butterfly (6 VALU): quad xor 1, xor 2, row_half_mirror, row_mirror give every lane its row
+// sum; row_bcast:15 adds each row's predecessor, row_bcast:31 then adds rows 0+1 into row 3.  u1 = total of v8 in lanes
+// 48..63 (other rows hold partial sums nobody reads).  Fixed tree -> deterministic.
+__device__ __forceinline__ void wave_sum9_halving(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                                  float v7, float v8, bool lane_bit3, float& u0, float& u1) {
+  const float r0 = swap32_add(v0, v1), r1 = swap32_add(v2, v3), r2 = swap32_add(v4, v5), r3 = swap32_add(v6, v7);
+  const float s0 = swap16_add(r0, r1), s1 = swap16_add(r2, r3);
+  const float keep = lane_bit3 ? s1 : s0;
+  const float send = lane_bit3 ? s0 : s1;
+  float a = keep + dpp_get<0x128>(send);   // row_ror:8
+  float b = v8 + dpp_get<0xB1>(v8);        // quad_perm:[1,0,3,2]
+  a += dpp_get<0xB1>(a);
+  b += dpp_get<0x4E>(b);                   // quad_perm:[2,3,0,1]
+  a += dpp_get<0x4E>(a);
+  b += dpp_get<0x141>(b);                  // row_half_mirror
+  a += dpp_get<0x141>(a);
+  b += dpp_get<0x140>(b);                  // row_mirror
+  b += dpp_get<0x142>(b);                  // row_bcast:15: row k += row k-1  (row 3 = r3 + r2, row 1 = r1 + r0)
+  b += dpp_get<0x143>(b);                  // row_bcast:31: row 3 += lane 31 = r1 + r0   (rows 0..2: don't care)
+  u0 = a;
+  u1 = b;
+}
+
+// test hook (tests/test_parity_gpu.py::test_wave_reduction_primitive): in[10][64] -> out[0..9] (ten-value tree) and
+// out[10..18] (nine-value tree on rows 0..8) through the same store patterns the render backward uses
 __global__ void k_debug_wave_reduce(const float* __restrict__ in, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   float u0, u1;
@@ -78,10 +104,15 @@ __global__ void k_debug_wave_reduce(const float* __restrict__ in, float* __restr
   const int val = ((o & 1) << 2) | (o & 2) | ((o & 4) >> 2);   // {0,4,2,6,1,5,3,7}[o]
   if ((lane & 7) == 0) out[val] = u0;
   if ((lane & 31) == 0) out[8 + (lane >> 5)] = u1;
+  // nine-value variant on the first nine rows -> out[10..18]
+  wave_sum9_halving(in[0 * 64 + lane], in[1 * 64 + lane], in[2 * 64 + lane], in[3 * 64 + lane], in[4 * 64 + lane],
+                    in[5 * 64 + lane], in[6 * 64 + lane], in[7 * 64 + lane], in[8 * 64 + lane], (lane & 8) != 0, u0, u1);
+  if ((lane & 7) == 0) out[10 + val] = u0;
+  if (lane == 63) out[18] = u1;
 }
 
-extern "C" int gsr_debug_wave_reduce(const float* in640, float* out10, void* stream) {
-  hipLaunchKernelGGL(k_debug_wave_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, in640, out10);
+extern "C" int gsr_debug_wave_reduce(const float* in640, float* out20, void* stream) {
+  hipLaunchKernelGGL(k_debug_wave_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, in640, out20);
   return gsr_check(hipGetLastError(), "debug wave reduce");
 }
 
@@ -195,7 +226,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
                                                     const float* __restrict__ dL_dinvdepth,
                                                     const uint32_t* __restrict__ slot_of_pos,
                                                     float4* __restrict__ igrad) {
-  __shared__ float4 s0[BWD_BATCH + 2], s1[BWD_BATCH + 2], s2[BWD_BATCH + 2];
+  __shared__ float4 s0[BWD_BATCH + 6], s1[BWD_BATCH + 6], s2[BWD_BATCH];  // +6: the prefetch may touch [n+5]
   // one private slab per wave: no LDS atomics, and the 4 partial sums are added in a FIXED order at flush time,
   // so gradients are bitwise reproducible
   __shared__ float4 slab[4][BWD_BATCH * GSR_IGRAD_F4];
@@ -249,10 +280,18 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
   float T = T_final;
   // The published per-channel recurrence "colour accumulated behind" ar_c enters the gradient only through
   // sum_c (c_c - ar_c) gp_c, and the recurrence is linear, so ONE scalar S = sum_c ar_c gp_c (the loss-weighted colour
-  // behind this pixel, depth channel included) carries it:  S <- la * (c_prev . gp) + (1 - la) * S.
-  float S = 0.f, last_cg = 0.f, last_alpha = 0.f;
+  // behind this pixel, depth channel included) carries it.  After an entry with alpha a and colour c:
+  // S <- a (c . gp) + (1 - a) S = S + a (c . gp - S), and (c . gp - S) is the very term dL/dalpha needs: one fma.
+  float S = 0.f;
   float4* myslab = slab[w];
-  const bool lane_bit3 = (lane & 8) != 0, octet_lead = (lane & 7) == 0, half_lead = (lane & 31) == 0;
+  // The staged records are read at wave-uniform addresses; a zero the compiler cannot see through keeps the base in a
+  // VGPR (ds_read takes its address from one), advanced once per trip, instead of an SGPR re-copied before every read.
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  const float4 *s0v = s0 + vzero, *s1v = s1 + vzero, *s2v = s2 + vzero;
+  const bool lane_bit3 = (lane & 8) != 0, octet_lead = (lane & 7) == 0;
+  const bool u1_lead = DEPTH ? (lane & 31) == 0 : lane == 63;   // lanes holding the v8 / v9 totals
+  const int u1_slot = DEPTH ? 8 + (lane >> 5) : 8;
   const int octet_val = (((lane >> 3) & 1) << 2) | ((lane >> 3) & 2) | (((lane >> 3) & 4) >> 2);
 
   for (int b = 0; b < rounds; b++) {
@@ -282,11 +321,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
       const bool pre = entry1 <= last && power >= bb.z;   // conservative wave-level reject (see forward)
       if (BALLOT(pre) == 0ull) return;
-      const float G = __expf(power);
+      const float G = (pre && power <= 0.0f) ? __expf(power) : 0.f;
       const float alpha = fminf(0.99f, bb.y * G);
-      const bool ok = pre && power <= 0.0f && alpha >= ALPHA_MIN;
+      const bool ok = alpha >= ALPHA_MIN;                     // ballot straight off one v_cmp
       if (BALLOT(ok) == 0ull) return;
-      const float4 c = s2[j];
+      const float4 c = s2v[j];
       // Lanes that do not blend this entry run the same arithmetic with alpha = G = 0: T, the "accumulated behind"
       // recurrences and every gradient term then stay exactly unchanged / zero, so no per-lane branch is needed.
       const float a_e = ok ? alpha : 0.f;
@@ -296,10 +335,9 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       const float dch = a_e * T;
       float cg = bb.w * gp0 + c.x * gp1 + c.y * gp2;                  // this entry's colour . dL/dpixel
       if (DEPTH) cg += c.z * gd;
-      S = last_alpha * last_cg + (1.f - last_alpha) * S;
-      last_cg = cg;
-      last_alpha = a_e;
-      const float dL_dalpha = (cg - S) * T + neg_Tf_bg * rcp;
+      const float diff = cg - S;
+      S = __builtin_fmaf(a_e, diff, S);
+      const float dL_dalpha = diff * T + neg_Tf_bg * rcp;
       const float v6 = dch * gp0, v7 = dch * gp1, v8 = dch * gp2, v9 = DEPTH ? dch * gd : 0.f;
       // Geometry: only the raw moments of g = dL/dpower = G alpha-gradient are reduced here; the per-Gaussian linear map
       // to (dL/dmean2D, dL/dconic) uses wave-uniform factors (conic, W/2, H/2) and is applied once per Gaussian AFTER the
@@ -309,18 +347,26 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       const float v0 = g * dx, v1 = g * dy;                           // sum g dx, sum g dy
       const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;           // sum g dx^2, g dx dy, g dy^2
       float u0, u1;
-      wave_sum10_halving(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, lane_bit3, u0, u1);
+      if (DEPTH) wave_sum10_halving(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, lane_bit3, u0, u1);
+      else wave_sum9_halving(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane_bit3, u0, u1);
       float* dst = reinterpret_cast<float*>(myslab) + 12 * j;
       if (octet_lead) dst[octet_val] = u0;        // 8 lanes store v0..v7 totals
-      if (half_lead) dst[8 + (lane >> 5)] = u1;   // lanes 0 / 32 store v8 / v9
+      if (u1_lead) dst[u1_slot] = u1;             // v8 (/ v9) totals
     };
-    float4 a0 = s0[0], b0 = s1[0];
-    for (int j = 0; j < n; j += 2) {
-      const float4 a1 = s0[j + 1], b1 = s1[j + 1];
+    // four entries per trip, records prefetched two entries ahead into rotating register sets; constant LDS offsets from
+    // one base per trip (no per-entry address arithmetic)
+    float4 a0 = s0v[0], b0 = s1v[0], a1 = s0v[1], b1 = s1v[1];
+    for (int j = 0; j < n; j += 4) {
+      const float4 a2 = s0v[j + 2], b2 = s1v[j + 2];
       step(a0, b0, j);
-      a0 = s0[j + 2];
-      b0 = s1[j + 2];
+      const float4 a3 = s0v[j + 3], b3 = s1v[j + 3];
       if (j + 1 < n) step(a1, b1, j + 1);
+      a0 = s0v[j + 4];
+      b0 = s1v[j + 4];
+      if (j + 2 < n) step(a2, b2, j + 2);
+      a1 = s0v[j + 5];
+      b1 = s1v[j + 5];
+      if (j + 3 < n) step(a3, b3, j + 3);
     }
     __syncthreads();
     // flush: 128 entries x 3 float4 = 384 float4, fixed summation order over the 4 waves

@@ -136,8 +136,9 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, u
 int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float** rec48, const uint32_t** depth_keys_sorted,
                              const uint32_t** order, const uint32_t** tiles_touched, const uint16_t** rect,
                              const uint32_t** offsets);
-/* test hook: ten 64-lane sums through the render backward's cross-lane reduction; in[10][64] -> out[10] */
-int gsr_debug_wave_reduce(const float* in640, float* out10, void* stream);
+/* test hook: 64-lane sums through the render backward's cross-lane reductions; in[10][64] -> out[20]:
+ * out[0..9] = the ten-value tree, out[10..18] = the nine-value tree on rows 0..8, out[19] unused */
+int gsr_debug_wave_reduce(const float* in640, float* out20, void* stream);
 int gsr_debug_binning_views(const void* binning_state, int32_t image_width, int32_t image_height,
                             int64_t num_rendered, const uint32_t** point_list, const uint32_t** ranges);
 int gsr_debug_image_views(const void* image_state, int32_t image_width, int32_t image_height,
