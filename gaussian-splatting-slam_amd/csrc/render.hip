@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
                                                     const float4* __restrict__ rec, const float* __restrict__ bg,
                                                     float* __restrict__ out_color, float* __restrict__ out_invdepth,
                                                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-  __shared__ float4 s0[FWD_BATCH + 2], s1[FWD_BATCH + 2], s2[FWD_BATCH + 2];  // +2: the prefetch may touch [n+1]
+  __shared__ float4 s0[FWD_BATCH + 6], s1[FWD_BATCH + 6], s2[FWD_BATCH];  // +6: the prefetch may touch [n+5]
   const int tile = blockIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -138,15 +138,19 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   int toDo = (int)(range.y - range.x);
   const int rounds = (toDo + FWD_BATCH - 1) / FWD_BATCH;
 
-  bool done = !inside;
-  // A finished (or outside) pixel is moved far away: its power becomes hugely negative and fails the wave-level
-  // reject test with no extra instruction in the loop.
-  float pxe = done ? 1.0e15f : pxf;
+  // A finished (or outside) pixel is moved far away: its power becomes hugely negative, so it fails the wave-level
+  // reject test AND the exact alpha test (alpha = 0) with no extra instruction in the loop; "done" is never tested per
+  // lane.  `live` (wave-uniform, SGPR pair) holds the lanes still compositing.
+  float pxe = inside ? pxf : 1.0e15f;
+  uint64_t live = BALLOT(inside);
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   uint32_t last = 0;
+  int vzero;   // keeps the LDS base in a VGPR (see k_render_bwd)
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  const float4 *s0v = s0 + vzero, *s1v = s1 + vzero, *s2v = s2 + vzero;
 
   for (int r = 0; r < rounds; r++, toDo -= FWD_BATCH) {
-    if (__syncthreads_count(done) == 256) break;
+    if (__syncthreads_count(pxe > 1.0e14f) == 256) break;
     const uint32_t progress = range.x + (uint32_t)(r * FWD_BATCH + tid);
     if (progress < range.y) {
       const uint32_t id32 = point_list[progress];
@@ -163,7 +167,6 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
     }
     __syncthreads();
     const int n = toDo < FWD_BATCH ? toDo : FWD_BATCH;
-    bool wave_live = BALLOT(!done) != 0ull;
     // one list entry against this wave's 64 pixels
     auto step = [&](const float4& a, const float4& b, const int j) __attribute__((always_inline)) {
       const float dx = a.x - pxe, dy = a.y - pyf;
@@ -171,8 +174,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
       // conservative wave-level reject (b.z = -ln(255 opacity) - margin): no lane can reach alpha >= 1/255
       if (BALLOT(power >= b.z) != 0ull) {
         const float alpha = fminf(0.99f, b.y * __expf(power));
-        const bool ok = !done && power <= 0.0f && alpha >= ALPHA_MIN;
-        const float4 c = s2[j];
+        const bool ok = power <= 0.0f && alpha >= ALPHA_MIN;
+        const float4 c = s2v[j];
         const float test_T = T * (1.0f - alpha);
         const bool stop = ok && test_T < 0.0001f;    // the stopping Gaussian is NOT blended (A.5)
         const bool blend = ok && !stop;
@@ -183,19 +186,24 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
         D += c.z * wgt;
         T = blend ? test_T : T;
         last = blend ? (uint32_t)(r * FWD_BATCH + j + 1) : last;
-        done = done || stop;
-        pxe = done ? 1.0e15f : pxf;
-        wave_live = BALLOT(!done) != 0ull;           // `done` only changes here: whole quadrant saturated -> leave
+        pxe = stop ? 1.0e15f : pxe;
+        // (ballots taken straight off the three compares: the AND happens on the scalar unit)
+        live &= ~(BALLOT(power <= 0.0f) & BALLOT(alpha >= ALPHA_MIN) & BALLOT(test_T < 0.0001f));  // quadrant saturated -> leave
       }
     };
-    // software prefetch, two register sets in ping-pong (entry j+1 / j+2 in flight while j / j+1 is evaluated)
-    float4 a0 = s0[0], b0 = s1[0];
-    for (int j = 0; j < n && wave_live; j += 2) {
-      const float4 a1 = s0[j + 1], b1 = s1[j + 1];
+    // four entries per trip, records prefetched two entries ahead into rotating register sets
+    float4 a0 = s0v[0], b0 = s1v[0], a1 = s0v[1], b1 = s1v[1];
+    for (int j = 0; j < n && live != 0ull; j += 4) {
+      const float4 a2 = s0v[j + 2], b2 = s1v[j + 2];
       step(a0, b0, j);
-      a0 = s0[j + 2];
-      b0 = s1[j + 2];
-      if (j + 1 < n && wave_live) step(a1, b1, j + 1);
+      const float4 a3 = s0v[j + 3], b3 = s1v[j + 3];
+      if (j + 1 < n && live != 0ull) step(a1, b1, j + 1);
+      a0 = s0v[j + 4];
+      b0 = s1v[j + 4];
+      if (j + 2 < n && live != 0ull) step(a2, b2, j + 2);
+      a1 = s0v[j + 5];
+      b1 = s1v[j + 5];
+      if (j + 3 < n && live != 0ull) step(a3, b3, j + 3);
     }
   }
   if (inside) {
