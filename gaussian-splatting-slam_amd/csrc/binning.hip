@@ -38,13 +38,12 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
       const ushort4 r = rect[g];
       // same inputs (the stored record) and the same compiled row-interval routine as k_preprocess_fwd -> exactly n tiles
       const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1];
-      const float q = -2.0f * r1.z;
       const uint32_t end = off + n;
       uint32_t* kdst = staged ? lkey : tile_key;
       uint32_t* gdst = staged ? lgid : gauss_of_slot;
       const uint32_t bias = staged ? slot0 : 0u;
       for (int y = r.y; y < r.w; y++) {
-        const uint32_t iv = gsr_row_interval(r0.x, r0.y, r0.z, r0.w, r1.x, q, y, r.x, r.z);
+        const uint32_t iv = gsr_row_interval(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z, y, r.x, r.z);
         const int lo = (int)(iv & 0xFFFFu), hi = (int)(iv >> 16);
         for (int x = lo; x < hi && off < end; x++) {
           kdst[off - bias] = (uint32_t)(y * grid_x + x);

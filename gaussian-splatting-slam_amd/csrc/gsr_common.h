@@ -11,12 +11,16 @@
 #define GSR_TILE_PIX 256
 #define GSR_WAVE 64
 #define GSR_REC_F4 3                // packed splat record = 3 float4 = 48 B
+// The record stores the conic as the render kernels consume it: log2(alpha/opacity) = (As dx + Bs dy) dx + Cs dy dy with
+// As = -0.5 log2(e) A, Bs = -log2(e) B, Cs = -0.5 log2(e) C, and the cut-off pmin scaled by log2(e) likewise: five VALU
+// and a bare v_exp_f32 per (pixel, Gaussian) instead of seven and a multiply.
+#define GSR_LOG2E 1.4426950408889634f
 #define GSR_IGRAD_F4 3              // per-instance gradient record = 3 float4 (10 used)
 
 // -------------------------------------------------------------------------------------------------
 // Packed per-Gaussian splat record written by preprocess and staged through LDS by the render kernels:
 //   r0 = (mean2D.x, mean2D.y, conic.A, conic.B)
-//   r1 = (conic.C, opacity*aa, pmin = -ln(255 opacity*aa) - margin, rgb.r)
+//   r1 = (conic.C, opacity*aa, pmin = -ln(255 opacity*aa) - margin, rgb.r)      conic and pmin in the scaled form above
 //   r2 = (rgb.g, rgb.b, 1/depth, depth)
 // r0 + r1 are all a wave needs to reject a Gaussian for its 64 pixels; r2 is read on hits only.
 // One 48-B gather per (tile, instance) instead of four separate arrays.
@@ -167,8 +171,12 @@ __device__ __forceinline__ int gsr_lane() { return threadIdx.x & 63; }
 // x-extent is [x_lo(y*), x_hi(y**)] with x_hi/lo(y) = (-B y +- sqrt(A q - det y^2)) / A evaluated at the band-clamped
 // heights of the ellipse's right-/left-most points.  Returns the half-open column interval clipped to [cx0, cx1) packed as
 // lo | hi << 16 (lo >= hi: empty).  __noinline__: ONE compiled body, so the count and the emission agree bit for bit.
-__device__ __noinline__ uint32_t gsr_row_interval(float mx, float my, float A, float B, float C, float q, int ty, int cx0,
-                                                  int cx1) {
+// Inputs are the STORED record fields (conic and cut-off pre-scaled for the render kernels, see GSR_K*): both callers pass
+// the same bits and the un-scaling happens in here, once.
+__device__ __noinline__ uint32_t gsr_row_interval(float mx, float my, float As, float Bs, float Cs, float pmins, int ty,
+                                                  int cx0, int cx1) {
+  const float A = As * (-2.0f / GSR_LOG2E), B = Bs * (-1.0f / GSR_LOG2E), C = Cs * (-2.0f / GSR_LOG2E);
+  const float q = pmins * (-2.0f / GSR_LOG2E);
   const float det = A * C - B * B;
   const float hy = sqrtf(fmaxf(0.f, q * A / det)) * 1.0001f + 0.01f;       // ellipse half-height (+ slack)
   const float yl = (float)(ty * GSR_TILE) - my, yh = yl + (float)(GSR_TILE - 1);

@@ -18,6 +18,12 @@
 
 #define ALPHA_MIN (1.0f / 255.0f)
 
+// log2 of the Gaussian falloff at d = mean - pixel from the pre-scaled conic of the record (gsr_common.h): 5 VALU
+__device__ __forceinline__ float gsr_power2(const float4& r0, const float4& r1, float dx, float dy) {
+  const float t = __builtin_fmaf(r0.w, dy, r0.z * dx);
+  return __builtin_fmaf(r1.x * dy, dy, t * dx);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Ten full-wave sums by recursive halving: at every stage a lane keeps half of its values and hands the other half to
 // its partner, so the work per stage halves (10 -> 5 -> 3 -> 2 registers) instead of staying at ten DPP adds per stage.
@@ -170,10 +176,10 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
     // one list entry against this wave's 64 pixels
     auto step = [&](const float4& a, const float4& b, const int j) __attribute__((always_inline)) {
       const float dx = a.x - pxe, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      // conservative wave-level reject (b.z = -ln(255 opacity) - margin): no lane can reach alpha >= 1/255
+      const float power = gsr_power2(a, b, dx, dy);
+      // conservative wave-level reject (b.z = log2 of 1/(255 opacity), minus a margin): no lane can reach alpha >= 1/255
       if (BALLOT(power >= b.z) != 0ull) {
-        const float alpha = fminf(0.99f, b.y * __expf(power));
+        const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
         const bool ok = power <= 0.0f && alpha >= ALPHA_MIN;
         const float4 c = s2v[j];
         const float test_T = T * (1.0f - alpha);
@@ -326,10 +332,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
     auto step = [&](const float4& a, const float4& bb, const int j) __attribute__((always_inline)) {
       const int entry1 = toDo - (b * BWD_BATCH + j);  // 1-based list position of this entry
       const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+      const float power = gsr_power2(a, bb, dx, dy);
       const bool pre = entry1 <= last && power >= bb.z;   // conservative wave-level reject (see forward)
       if (BALLOT(pre) == 0ull) return;
-      const float G = (pre && power <= 0.0f) ? __expf(power) : 0.f;
+      const float G = (pre && power <= 0.0f) ? __builtin_amdgcn_exp2f(power) : 0.f;
       const float alpha = fminf(0.99f, bb.y * G);
       const bool ok = alpha >= ALPHA_MIN;                     // ballot straight off one v_cmp
       if (BALLOT(ok) == 0ull) return;
