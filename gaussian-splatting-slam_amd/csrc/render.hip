@@ -273,12 +273,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
   // entries beyond the deepest contributor of any pixel are never visited
   if (tid == 0) s_max = 0;
   __syncthreads();
-  {
-    int m = last;
+  int wave_last = last;   // deepest contributor among this wave's 64 pixels
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-    if (lane == 0) atomicMax(&s_max, m);
-  }
+  for (int d = 32; d > 0; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d, 64));
+  wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+  if (lane == 0) atomicMax(&s_max, wave_last);
   __syncthreads();
   const int toDo = min(len, s_max);
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -334,11 +333,13 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       const float dx = a.x - pxf, dy = a.y - pyf;
       const float power = gsr_power2(a, bb, dx, dy);
       const bool pre = entry1 <= last && power >= bb.z;   // conservative wave-level reject (see forward)
-      if (BALLOT(pre) == 0ull) return;
-      const float G = (pre && power <= 0.0f) ? __builtin_amdgcn_exp2f(power) : 0.f;
+      // (every ballot is taken straight off ONE compare; the ANDs run on the scalar unit)
+      const uint64_t m_pre = BALLOT(entry1 <= last) & BALLOT(power >= bb.z);
+      if (m_pre == 0ull) return;
+      const float G = __builtin_amdgcn_exp2f(power);
       const float alpha = fminf(0.99f, bb.y * G);
-      const bool ok = alpha >= ALPHA_MIN;                     // ballot straight off one v_cmp
-      if (BALLOT(ok) == 0ull) return;
+      const bool ok = pre && power <= 0.0f && alpha >= ALPHA_MIN;
+      if ((m_pre & BALLOT(power <= 0.0f) & BALLOT(alpha >= ALPHA_MIN)) == 0ull) return;
       const float4 c = s2v[j];
       // Lanes that do not blend this entry run the same arithmetic with alpha = G = 0: T, the "accumulated behind"
       // recurrences and every gradient term then stay exactly unchanged / zero, so no per-lane branch is needed.
@@ -369,8 +370,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
     };
     // four entries per trip, records prefetched two entries ahead into rotating register sets; constant LDS offsets from
     // one base per trip (no per-entry address arithmetic)
-    float4 a0 = s0v[0], b0 = s1v[0], a1 = s0v[1], b1 = s1v[1];
-    for (int j = 0; j < n; j += 4) {
+    // entries deeper than this wave's deepest contributor come first in the back-to-front order: skip them wholesale
+    const int jstart = max(0, (toDo - b * BWD_BATCH) - wave_last) & ~3;
+    float4 a0 = s0v[jstart], b0 = s1v[jstart], a1 = s0v[jstart + 1], b1 = s1v[jstart + 1];
+    for (int j = jstart; j < n; j += 4) {
       const float4 a2 = s0v[j + 2], b2 = s1v[j + 2];
       step(a0, b0, j);
       const float4 a3 = s0v[j + 3], b3 = s1v[j + 3];
