@@ -82,6 +82,8 @@ EXPORTS = {
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                        C.c_void_p]),
     "gsr_densification_stats": (C.c_int, [C.c_int64] + [C.c_void_p] * 6),
+    "gsr_gaussian_activations_forward": (C.c_int, [C.c_int32] + [C.c_void_p] * 7),
+    "gsr_gaussian_activations_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 10),
     "gsr_densify_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gsr_densify_plan": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64),

@@ -24,12 +24,10 @@ class PipelineParams:
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, separate_sh=False,
            override_color=None, use_trained_exp=False):
     # zero tensor that receives the screen-space (NDC) gradient of the 2-D means (reference :26-30)
+    # (a leaf here: its .grad is what the callers read; the reference's `+ 0` / retain_grad() pair gives the same .grad at
+    # the price of one more launch per step)
     screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
-                                          device=pc.get_xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+                                          device=pc.get_xyz.device)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
@@ -52,14 +50,20 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     means3D = pc.get_xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity
 
     scales = rotations = cov3D_precomp = None
-    if pipe.compute_cov3D_python:
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    # A model that offers the fused activation op (scene_utils.model.GaussianModel.get_activated: one launch for exp /
+    # normalize / sigmoid) is asked for all three at once; any other model object goes through the reference's getters.
+    fused = getattr(pc, "get_activated", None)
+    if fused is not None and not pipe.compute_cov3D_python:
+        scales, rotations, opacity = fused()
     else:
-        scales = pc.get_scaling
-        rotations = pc.get_rotation
+        opacity = pc.get_opacity
+        if pipe.compute_cov3D_python:
+            cov3D_precomp = pc.get_covariance(scaling_modifier)
+        else:
+            scales = pc.get_scaling
+            rotations = pc.get_rotation
 
     shs = colors_precomp = dc = None
     if override_color is None:

@@ -86,6 +86,15 @@ class GaussianModel:
     def get_opacity(self):
         return torch.sigmoid(self._opacity)
 
+    def get_activated(self):
+        """(scaling, rotation, opacity) as get_scaling / get_rotation / get_opacity return them, through ONE fused HIP
+        launch (and one in the backward) when the parameters live on the device; render() prefers this when the model
+        offers it.  CPU tensors (host-logic tests) take the plain torch getters."""
+        if self._scaling.is_cuda:
+            from .activations import gaussian_activations
+            return gaussian_activations(self._scaling, self._rotation, self._opacity)
+        return self.get_scaling, self.get_rotation, self.get_opacity
+
     def get_covariance(self, scaling_modifier=1):
         """reference scene/gaussian_model.py:32-36 (note: passes the RAW rotation; build_rotation normalises)."""
         R = _build_rotation(self._rotation)

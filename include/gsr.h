@@ -199,6 +199,19 @@ int gsr_densify_apply(int64_t P, const void* workspace, const float* const* in_p
                       const int32_t* row_floats, int64_t n_keep, int64_t n_clone, int64_t n_child, uint32_t seed,
                       int32_t* source_of_row, void* stream);
 
+/* The model's parameter activations, fused (reference scene/gaussian_model.py:38-46 setup_functions, :101-121 getters):
+ * scaling = exp(_scaling) [P,3], rotation = normalize(_rotation) = x / max(|x|, 1e-12) [P,4], opacity = sigmoid(_opacity)
+ * [P,1]; what render() reads through pc.get_scaling / get_rotation / get_opacity (gaussian_renderer/__init__.py:55-62).
+ * One launch each way instead of ~25 elementwise / reduce launches per training step.
+ * backward: dL_d* of the three outputs (any may be NULL = zero) -> gradients of the raw parameters (always written). */
+int gsr_gaussian_activations_forward(int32_t P, const float* raw_scaling, const float* raw_rotation,
+                                     const float* raw_opacity, float* scaling, float* rotation, float* opacity,
+                                     void* stream);
+int gsr_gaussian_activations_backward(int32_t P, const float* raw_rotation, const float* scaling, const float* opacity,
+                                      const float* dL_dscaling, const float* dL_drotation, const float* dL_dopacity,
+                                      float* dL_draw_scaling, float* dL_draw_rotation, float* dL_draw_opacity,
+                                      void* stream);
+
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline block). */
 void gsr_profile_enable(int32_t on);
 void gsr_profile_reset(void);

@@ -1,0 +1,88 @@
+"""Fused parameter activations (gsr_gaussian_activations_*) against the three PyTorch ops the reference's model uses
+(scene/gaussian_model.py:38-46: torch.exp, torch.nn.functional.normalize, torch.sigmoid), forward and backward.
+Tolerance: fp32 round-off of a handful of operations (rtol 2e-6 / atol 1e-7 forward, 1e-5 relative on gradients)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw(P, seed):
+    g = torch.Generator().manual_seed(seed)
+    s = (torch.randn(P, 3, generator=g) * 1.5 - 3.0)
+    q = torch.randn(P, 4, generator=g) * torch.rand(P, 1, generator=g) * 3.0
+    o = torch.randn(P, 1, generator=g) * 3.0
+    return s, q, o
+
+
+def test_fused_activations_match_torch_ops():
+    from scene_utils.activations import gaussian_activations
+    for P in (1, 255, 4099):
+        s0, q0, o0 = _raw(P, 3 + P)
+        a = [t.clone().cuda().requires_grad_(True) for t in (s0, q0, o0)]
+        b = [t.clone().cuda().requires_grad_(True) for t in (s0, q0, o0)]
+        fs, fq, fo = gaussian_activations(*a)
+        ts, tq, to = torch.exp(b[0]), torch.nn.functional.normalize(b[1]), torch.sigmoid(b[2])
+        for f, t in ((fs, ts), (fq, tq), (fo, to)):
+            assert f.shape == t.shape
+            torch.testing.assert_close(f, t, rtol=2e-6, atol=1e-7)
+        g = torch.Generator().manual_seed(11)
+        ws, wq, wo = (torch.randn(t.shape, generator=g).cuda() for t in (ts, tq, to))
+        ((fs * ws).sum() + (fq * wq).sum() + (fo * wo).sum()).backward()
+        ((ts * ws).sum() + (tq * wq).sum() + (to * wo).sum()).backward()
+        for x, y in zip(a, b):
+            torch.testing.assert_close(x.grad, y.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_activations_partial_gradients_and_degenerate_quaternion():
+    from scene_utils.activations import gaussian_activations
+    s0, q0, o0 = _raw(300, 5)
+    q0[7] = 0.0                                   # |q| < eps: forward 0/eps = 0, gradient g/eps like F.normalize
+    a = [t.clone().cuda().requires_grad_(True) for t in (s0, q0, o0)]
+    b = [t.clone().cuda().requires_grad_(True) for t in (s0, q0, o0)]
+    fs, fq, fo = gaussian_activations(*a)
+    assert torch.equal(fq[7], torch.zeros(4, device="cuda"))
+    (fq[:, 1] * 2.0).sum().backward()             # only the rotation output is used: the other two gradients arrive as None
+    (torch.nn.functional.normalize(b[1])[:, 1] * 2.0).sum().backward()
+    keep = torch.ones(300, dtype=torch.bool); keep[7] = False
+    torch.testing.assert_close(a[1].grad[keep.cuda()], b[1].grad[keep.cuda()], rtol=1e-5, atol=1e-6)
+    assert torch.isfinite(a[1].grad).all()
+    assert torch.count_nonzero(a[0].grad) == 0 and torch.count_nonzero(a[2].grad) == 0
+
+
+def test_render_uses_fused_activations_with_same_result():
+    """render() asks a model that offers get_activated() for the fused triple; image and parameter gradients equal the
+    getter path's."""
+    from gaussian_renderer import PipelineParams, render
+    from scene_utils.cameras import look_at_camera
+    from scene_utils.model import GaussianModel
+    from scene_utils.synthetic import make_gaussians
+
+    raw = make_gaussians(1500, 3, seed=9)
+    cam = look_at_camera((0.0, -4.0, 0.5), (0, 0, 0), (0, 0, 1), 1.0, 96, 64).to("cuda")
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    pipe = PipelineParams()
+
+    class GetterOnly:                                  # the reference's interface: no get_activated
+        def __init__(self, m):
+            self._m = m
+        active_sh_degree = property(lambda self: self._m.active_sh_degree)
+        max_sh_degree = property(lambda self: self._m.max_sh_degree)
+        get_xyz = property(lambda self: self._m.get_xyz)
+        get_opacity = property(lambda self: self._m.get_opacity)
+        get_scaling = property(lambda self: self._m.get_scaling)
+        get_rotation = property(lambda self: self._m.get_rotation)
+        get_features = property(lambda self: self._m.get_features)
+
+    outs = []
+    for wrap in (lambda m: m, GetterOnly):
+        m = GaussianModel.from_raw(raw.to("cuda"))
+        pkg = render(cam, wrap(m), pipe, bg)
+        pkg["render"].square().sum().backward()
+        outs.append((pkg["render"].detach(), [p.grad.clone() for p in (m._xyz, m._scaling, m._rotation, m._opacity)],
+                     pkg["viewspace_points"].grad.clone()))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+    # gradients: sums over pixels with cancellation, and the two paths round the activations differently in the last bit:
+    # 2e-4 relative, with an absolute floor of 1e-5 of the largest entry
+    for x, y in zip(outs[0][1] + [outs[0][2]], outs[1][1] + [outs[1][2]]):
+        torch.testing.assert_close(x, y, rtol=2e-4, atol=1e-5 * float(y.abs().max()))
