@@ -128,6 +128,12 @@ static uint32_t* pinned_slot() {
   return p;
 }
 
+static hipEvent_t readback_event() {
+  static thread_local hipEvent_t ev = nullptr;
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+  return ev;
+}
+
 static int tile_bits(int tiles) {
   int b = 1;
   while ((1 << b) < tiles) b++;
@@ -207,6 +213,15 @@ static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* 
   gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
 
+  // num_rendered (meta[2..3], counted by the preprocess kernel) and the error flags go back to the host NOW; the depth sort
+  // and the offset scan are enqueued behind the copy and keep the GPU busy while the host waits for the two words, sizes
+  // the binning state and enqueues the binning / render stages: no idle gap at the one read-back this path needs.
+  uint32_t* host = pinned_slot();
+  hipEvent_t ev = readback_event();
+  if (!host || !ev) { gsr_set_error("hipHostMalloc / hipEventCreate failed"); return GSR_ERR_HIP; }
+  if ((rc = gsr_check(hipMemcpyAsync(&host[0], meta, 16, hipMemcpyDeviceToHost, st), "read num_rendered"))) return rc;
+  if ((rc = gsr_check(hipEventRecord(ev, st), "record read-back event"))) return rc;
+
   // depth order of the Gaussians (stable, so equal depths keep ascending id); 4 passes -> result in (depth_key, order)
   const int where = gsr_radix_sort_pairs((uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order),
                                          (uint32_t*)(geom + L.key_tmp), (uint32_t*)(geom + L.val_tmp),
@@ -214,27 +229,22 @@ static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* 
   if (where != 0) { gsr_set_error("internal: depth sort ended in the wrong buffer"); return GSR_ERR_HIP; }
   if ((rc = debug_sync(s, st, "depth sort"))) return rc;
 
-  // inclusive prefix sum of tiles_touched in depth order
+  // inclusive prefix sum of tiles_touched in depth order (its last element equals num_rendered)
   gsr_scan_u32((const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.order),
                (uint32_t*)(geom + L.offsets), (size_t)P, 1, (uint32_t*)(geom + L.scan_tmp), st);
   if ((rc = debug_sync(s, st, "tile-count scan"))) return rc;
 
-  uint32_t* host = pinned_slot();
-  if (!host) { gsr_set_error("hipHostMalloc failed"); return GSR_ERR_HIP; }
-  if ((rc = gsr_check(hipMemcpyAsync(&host[0], (uint32_t*)(geom + L.offsets) + (P - 1), 4, hipMemcpyDeviceToHost, st),
-                      "read num_rendered")))
-    return rc;
-  if ((rc = gsr_check(hipMemcpyAsync(&host[1], meta + 1, 4, hipMemcpyDeviceToHost, st), "read flags"))) return rc;
-  if ((rc = gsr_check(hipStreamSynchronize(st), "sync after prepare"))) return rc;
+  if ((rc = gsr_check(hipEventSynchronize(ev), "wait for num_rendered"))) return rc;
+  const unsigned long long total = (unsigned long long)host[2] | ((unsigned long long)host[3] << 32);
   if (host[1] & 1u) {
     gsr_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
     return GSR_ERR_PREFILTERED_CULLED;
   }
-  if (host[0] > 0x7FFFFFFFu) {
-    gsr_set_error("num_rendered %u does not fit 31 bits", host[0]);
+  if (total > 0x7FFFFFFFull) {
+    gsr_set_error("num_rendered %llu does not fit 31 bits", total);
     return GSR_ERR_TOO_MANY_INSTANCES;
   }
-  return (int64_t)host[0];
+  return (int64_t)total;
 }
 
 int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,

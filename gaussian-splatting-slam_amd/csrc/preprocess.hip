@@ -196,14 +196,16 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+  __shared__ uint32_t block_tiles;   // this workgroup's share of num_rendered
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int S = 3 * sh_stride, Sp = S | 1;
+  if (threadIdx.x == 0) block_tiles = 0;
   if (STAGE) {
     const size_t row0 = (size_t)blockIdx.x * 256;
     const int rows = (int)min((size_t)256, (size_t)P - row0);
     stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds);
-    __syncthreads();
   }
+  __syncthreads();
   if (idx >= P) return;
   const float* my_row = sh_lds + threadIdx.x * Sp;
   PreView v;
@@ -339,6 +341,12 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
   radii[idx] = out_radius;
   tiles_touched[idx] = out_tiles;
   depth_key[idx] = out_key;   // `order` is not written: the depth sort takes value = index on its first pass
+  // num_rendered = sum of tiles_touched does not depend on the depth order: counted here (integer atomics: exact), so the
+  // host can read it back while the depth sort and the offset scan are still running (api.hip: forward_prepare_impl).
+  if (out_tiles != 0) atomicAdd(&block_tiles, out_tiles);
+  __syncthreads();   // (threads past the end of the array have exited; the barrier counts live waves only)
+  if (threadIdx.x == 0 && block_tiles != 0)
+    atomicAdd(reinterpret_cast<unsigned long long*>(meta + 2), (unsigned long long)block_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------------

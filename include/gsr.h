@@ -101,8 +101,9 @@ size_t gsr_backward_scratch_bytes(int32_t P, int64_t num_rendered);
 
 /* Forward, phase 1: preprocess (projection, EWA covariance, SH->RGB), depth ordering and the tile-count
  * prefix sum.  Writes radii[P] (int32; 0 = culled; reference :118-121 `radii`, `visibility_filter`).
- * Synchronises `stream` once to read num_rendered back (the reference rasterizer has the same single
- * host sync).  Returns num_rendered >= 0 or an error code. */
+ * Waits once for num_rendered to arrive on the host (the reference rasterizer has the same single read-back); the
+ * count is taken right after the projection kernel, so on return the depth sort / prefix sum may still be running on
+ * `stream` - everything later is stream-ordered behind them.  Returns num_rendered >= 0 or an error code. */
 int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
                             size_t geometry_bytes, int32_t* radii, void* stream);
 
