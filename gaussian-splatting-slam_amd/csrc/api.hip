@@ -20,6 +20,7 @@ void gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const 
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
 void gsr_launch_emit(int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
+void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
                            float*, float*, uint32_t*, hipStream_t);
 void gsr_launch_render_bwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*,
@@ -213,9 +214,10 @@ static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* 
   gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
 
-  // num_rendered (meta[2..3], counted by the preprocess kernel) and the error flags go back to the host NOW; the depth sort
+  // num_rendered (meta[2..3]) and the error flags go back to the host NOW; the depth sort
   // and the offset scan are enqueued behind the copy and keep the GPU busy while the host waits for the two words, sizes
   // the binning state and enqueues the binning / render stages: no idle gap at the one read-back this path needs.
+  gsr_launch_sum_tiles(P, geom, L, meta, st);
   uint32_t* host = pinned_slot();
   hipEvent_t ev = readback_event();
   if (!host || !ev) { gsr_set_error("hipHostMalloc / hipEventCreate failed"); return GSR_ERR_HIP; }

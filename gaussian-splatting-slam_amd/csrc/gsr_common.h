@@ -165,6 +165,22 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
 #ifdef __HIPCC__
 __device__ __forceinline__ int gsr_lane() { return threadIdx.x & 63; }
 
+// 16-B streaming (non-temporal) global accesses for data that passes through once
+typedef float gsr_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gsr_f4 gsr_ld_stream(const float* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const gsr_f4*>(p));
+}
+__device__ __forceinline__ void gsr_st_stream(float* p, gsr_f4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<gsr_f4*>(p));
+}
+__device__ __forceinline__ float4 gsr_ld_stream4(const float4* p) {
+  const gsr_f4 v = __builtin_nontemporal_load(reinterpret_cast<const gsr_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gsr_st_stream4(float4* p, const float4& v) {
+  __builtin_nontemporal_store(gsr_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<gsr_f4*>(p));
+}
+
 // Exact tile culling shared by preprocess (count) and emit (write).  Pixels that can blend a Gaussian satisfy
 // Q(d) = A dx^2 + 2B dx dy + C dy^2 <= q (q = -2 pmin, i.e. power >= pmin).  The part of that ellipse inside the horizontal
 // band of tile row ty (pixel centres 16ty .. 16ty+15) is convex, so the tile columns it reaches form ONE interval: its

@@ -117,7 +117,7 @@ __device__ __forceinline__ float sh_coef(const float* dc, const float* shs, int 
 __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int nflt, int S, int Sp, float* lds) {
   const int n4 = nflt >> 2;
   for (int i = threadIdx.x; i < n4; i += 256) {
-    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    const float4 v = gsr_ld_stream4(reinterpret_cast<const float4*>(src) + i);   // SH rows pass through once per kernel
     const int e = i * 4;
     int r = e / S, c = e - r * S;
     const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -143,7 +143,7 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, int nflt
       vv[k] = lds[r * Sp + c];
       if (++c == S) { c = 0; r++; }
     }
-    reinterpret_cast<float4*>(dst)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    gsr_st_stream4(reinterpret_cast<float4*>(dst) + i, make_float4(vv[0], vv[1], vv[2], vv[3]));
   }
   for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {
     const int r = e / S, c = e - r * S;
@@ -196,16 +196,14 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
-  __shared__ uint32_t block_tiles;   // this workgroup's share of num_rendered
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int S = 3 * sh_stride, Sp = S | 1;
-  if (threadIdx.x == 0) block_tiles = 0;
   if (STAGE) {
     const size_t row0 = (size_t)blockIdx.x * 256;
     const int rows = (int)min((size_t)256, (size_t)P - row0);
     stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds);
+    __syncthreads();
   }
-  __syncthreads();
   if (idx >= P) return;
   const float* my_row = sh_lds + threadIdx.x * Sp;
   PreView v;
@@ -341,12 +339,38 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
   radii[idx] = out_radius;
   tiles_touched[idx] = out_tiles;
   depth_key[idx] = out_key;   // `order` is not written: the depth sort takes value = index on its first pass
-  // num_rendered = sum of tiles_touched does not depend on the depth order: counted here (integer atomics: exact), so the
-  // host can read it back while the depth sort and the offset scan are still running (api.hip: forward_prepare_impl).
-  if (out_tiles != 0) atomicAdd(&block_tiles, out_tiles);
-  __syncthreads();   // (threads past the end of the array have exited; the barrier counts live waves only)
-  if (threadIdx.x == 0 && block_tiles != 0)
-    atomicAdd(reinterpret_cast<unsigned long long*>(meta + 2), (unsigned long long)block_tiles);
+}
+
+// num_rendered = sum of tiles_touched does not depend on the depth order: summed right after the projection (integer
+// atomics: exact), so the host can read it back while the depth sort and the offset scan are still running (api.hip:
+// forward_prepare_impl).  Same-address atomics cost ~15 ns each on this part, so: few workgroups, 16-B loads, one atomic per
+// workgroup.
+#define SUM_TILES_BLOCKS 128
+__global__ __launch_bounds__(256) void k_sum_tiles(int P, const uint32_t* __restrict__ tiles_touched,
+                                                   unsigned long long* __restrict__ total) {
+  __shared__ uint32_t wave_sum[4];
+  uint32_t acc = 0;
+  const int P4 = P >> 2;                                              // tiles_touched is 256-B aligned (gsr_geom_layout)
+  const uint4* v = reinterpret_cast<const uint4*>(tiles_touched);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < P4; i += gridDim.x * 256) {
+    const uint4 q = v[i];
+    acc += (q.x + q.y) + (q.z + q.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (P & 3)) acc += tiles_touched[4 * P4 + threadIdx.x];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);   // all 64 lanes are alive here
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long s = (unsigned long long)wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    if (s != 0) atomicAdd(total, s);
+  }
+}
+
+void gsr_launch_sum_tiles(int P, const char* geom, const GsrGeomLayout& L, uint32_t* meta, hipStream_t st) {
+  const int blocks = min(SUM_TILES_BLOCKS, (P + 1023) / 1024);
+  GSR_LAUNCH("sum_tiles", k_sum_tiles, dim3(blocks), dim3(256), 0, st, P, (const uint32_t*)(geom + L.tiles_touched),
+             reinterpret_cast<unsigned long long*>(meta + 2));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -455,6 +479,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     for (; it + 4 <= n; it += 4) {
       float4 q[12];
 #pragma unroll
+      // (plain loads on purpose: the records were just written by the render backward and are largely still in the
+      // infinity cache - streaming hints on either side cost 35 % here)
       for (int u = 0; u < 12; u++) q[u] = rows[3 * (size_t)it + u];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
