@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: exchange all gradients on the main stream (default overlaps the SH exchange + Adam with the next "
                          "step's geometry stages; same results, DESIGN.md 5)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="force the side-stream SH update on at N=1 too (default: on only for N>1, where it hides the exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
@@ -220,7 +222,7 @@ def main():
     trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=args.optimizer,
                       loss=args.loss, separate_sh=not args.concat_sh, depth_targets=depth_gts,
                       depth_weight=1.0 if depth_gts is not None else 0.0,
-                      overlap_comm=False if args.no_overlap else None)
+                      overlap_comm=False if args.no_overlap else (True if args.overlap else None))
     if args.densify:
         # cameras_extent of the reference = 1.1 x radius of the camera centres (scene/dataset_readers.py getNerfppNorm)
         trainer.enable_densification(extent=1.1 * 4.0, from_iter=args.densify_from)
