@@ -90,6 +90,22 @@ def pmc_traffic(kernel):
     return None
 
 
+def pmc_valu(kernel, avg_ms):
+    """VALU issue bound of `kernel` from the committed PMC pass (SQ_INSTS_VALU, wave-level instructions per launch at the C3
+    workload): a wave64 fp32 instruction occupies its SIMD's 16 lanes for 4 cycles, so the launch cannot finish faster than
+    insts x 4 / (1024 SIMDs x 2.4 GHz).  `issue_frac` = that bound / the measured duration."""
+    try:
+        data = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
+    except Exception:
+        return None
+    for name, v in data.items():
+        if name.split("<")[0] == "k_" + kernel and "valu_insts" in v:
+            bound_ms = v["valu_insts"] * 4.0 / (1024 * 2.4e9) * 1e3
+            return {"insts_per_launch": int(v["valu_insts"]), "issue_bound_ms": round(bound_ms, 4),
+                    "issue_frac": round(bound_ms / avg_ms, 3) if avg_ms else None}
+    return None
+
+
 def kernel_table(prof, R, N, P, M):
     """Algorithmic HBM bytes per launch (SURVEY.md 8(d) per-unit figures x units per launch; DESIGN.md 'Kernels')."""
     b_in = 44 + 12 * M
@@ -317,7 +333,9 @@ def main():
                                   "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBS, 5),
                                   "traffic": pmc_traffic(dom),
                                   "avg_ms": d["avg_ms"], "alg_bytes": d["alg_bytes"],
-                                  "note": "render kernels are FP32-VALU/LDS bound, not HBM bound (DESIGN.md)"}
+                                  "valu": pmc_valu(dom, d["avg_ms"]),
+                                  "note": "the render kernels are bound by FP32 VALU issue, not HBM: see `valu` "
+                                          "(DESIGN.md 4, 6); HBM fractions of the streaming kernels are in `kernels`"}
 
     log("extras done; cpu baseline next")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -37,6 +37,8 @@ def main():
             row["hbm_write_bytes"] = 1024 * st.mean(agg[k]["WRITE_SIZE"])
             latest[k] = {"read_bytes": row["hbm_read_bytes_corrected"], "write_bytes": row["hbm_write_bytes"],
                          "traffic_bytes": row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]}
+            if "SQ_INSTS_VALU" in agg[k]:      # wave-level VALU instructions per launch (issue-bound kernels)
+                latest[k]["valu_insts"] = st.mean(agg[k]["SQ_INSTS_VALU"])
         rows.append(row)
     fields = ["kernel", "dispatches"] + counters + ["hbm_read_bytes_corrected", "hbm_write_bytes"]
     with open(os.path.join(root, "profiles", name + ".csv"), "w") as fo:
