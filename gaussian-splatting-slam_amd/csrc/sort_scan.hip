@@ -184,18 +184,24 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ ta
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// Scatter pass.  Each workgroup owns one chunk of 4096 keys (16 per thread, element s*256+tid so that the original
-// order is (sub-tile, wave, lane)).  Phase 1 ranks every key inside its (chunk, digit) group with wave ballots (stable);
-// phase 2 sorts the chunk locally into LDS; phase 3 streams LDS out so that each digit's run lands in consecutive global
-// addresses (64-B+ runs instead of the 4-B scattered stores of a direct scatter).
+// Scatter pass.  Each workgroup owns one chunk of 4096 keys; wave w owns the contiguous quarter [1024 w, 1024 (w+1)) of it,
+// 16 sub-tiles of 64 keys, so the original order is (wave, sub-tile, lane).
+//   phase 1  every wave ranks its own keys inside their (wave, digit) group with ballots and a wave-PRIVATE LDS counter row:
+//            no workgroup barrier in the loop (LDS operations of one wave execute in order);
+//   phase 2  one barrier, then per digit: totals over the four waves, each wave's base inside the digit, local start of the
+//            digit (block scan) - the chunk is sorted locally into LDS;
+//   phase 3  LDS is streamed out so that each digit's run lands in consecutive global addresses (64-B+ runs instead of the
+//            4-B scattered stores of a direct scatter).
+// Stable: equal digits keep (wave, sub-tile, lane) = original order.
+#define GSR_RADIX_WAVE_KEYS (GSR_RADIX_CHUNK / 4)
+#define GSR_RADIX_WAVE_TILES (GSR_RADIX_WAVE_KEYS / 64)
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                        const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        const uint32_t* __restrict__ table_excl,
                                                        const uint32_t* __restrict__ totals, size_t n, int shift,
                                                        uint32_t mask, uint32_t nblk) {
-  __shared__ uint32_t digit_run[GSR_RADIX_SIZE];    // keys of each digit seen so far in this chunk -> final: local count
-  __shared__ uint32_t wave_cnt[4][GSR_RADIX_SIZE];
+  __shared__ uint32_t wave_run[4][GSR_RADIX_SIZE];  // phase 1: keys of (wave, digit) seen so far; phase 2: the wave's base
   __shared__ uint32_t lstart[GSR_RADIX_SIZE];       // first local (sorted) position of each digit
   __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
   __shared__ uint32_t lkeys[GSR_RADIX_CHUNK];
@@ -207,26 +213,29 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     const uint32_t digit_start = block_excl_scan_u32(totals[tid], &tot, lds4);   // keys with a smaller digit, whole array
     gbase[tid] = digit_start + table_excl[(size_t)tid * nblk + blockIdx.x];
   }
-  digit_run[tid] = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) wave_cnt[i][tid] = 0;
+  for (int i = 0; i < 4; i++) wave_run[i][tid] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * GSR_RADIX_CHUNK;
   const uint32_t count = (uint32_t)min((size_t)GSR_RADIX_CHUNK, n - base);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  uint32_t key[GSR_RADIX_SUBTILES], val[GSR_RADIX_SUBTILES], rk[GSR_RADIX_SUBTILES];   // rk = digit << 16 | local rank
+  const uint32_t wbase = (uint32_t)w * GSR_RADIX_WAVE_KEYS;
+  uint32_t* my_run = wave_run[w];
+  uint32_t key[GSR_RADIX_WAVE_TILES], val[GSR_RADIX_WAVE_TILES], rk[GSR_RADIX_WAVE_TILES];   // rk = digit << 16 | rank in (wave, digit)
 #pragma unroll
-  for (int s = 0; s < GSR_RADIX_SUBTILES; s++) {
-    const uint32_t li = (uint32_t)s * 256 + tid;
+  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++) {
+    const uint32_t li = wbase + (uint32_t)s * 64 + lane;
     const bool active = li < count;
-    uint32_t d = 0;
-    key[s] = 0; val[s] = 0;
-    if (active) {
-      key[s] = keys_in[base + li];
-      val[s] = vals_in ? vals_in[base + li] : (uint32_t)(base + li);
-      d = (key[s] >> shift) & mask;
-    }
-    if ((uint32_t)s * 256 < count) {   // block-uniform
+    key[s] = active ? keys_in[base + li] : 0u;
+    val[s] = active ? (vals_in ? vals_in[base + li] : (uint32_t)(base + li)) : 0u;
+  }
+#pragma unroll
+  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++) {
+    const uint32_t li = wbase + (uint32_t)s * 64 + lane;
+    const bool active = li < count;
+    const uint32_t d = active ? ((key[s] >> shift) & mask) : 0u;
+    rk[s] = 0;
+    if (wbase + (uint32_t)s * 64 < count) {   // wave-uniform
       unsigned long long peers = __ballot(active);
 #pragma unroll
       for (int b = 0; b < GSR_RADIX_BITS; b++) {
@@ -235,30 +244,29 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
         peers &= bit ? bal : ~bal;
       }
       const uint32_t rank = __popcll(peers & lt_mask);
-      if (active && rank == 0) wave_cnt[w][d] = __popcll(peers);
-      __syncthreads();
-      uint32_t off = digit_run[d] + rank;
-#pragma unroll
-      for (int i = 0; i < 3; i++)
-        if (i < w) off += wave_cnt[i][d];
-      rk[s] = (d << 16) | off;
-      __syncthreads();
-      digit_run[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
-#pragma unroll
-      for (int i = 0; i < 4; i++) wave_cnt[i][tid] = 0;
-      __syncthreads();
+      const uint32_t run = my_run[d];                                   // every lane of the group reads the same counter ...
+      rk[s] = (d << 16) | (run + rank);
+      if (active && rank == 0) my_run[d] = run + (uint32_t)__popcll(peers);   // ... before its first lane advances it
     }
   }
+  __syncthreads();
   {
+    // per digit (thread = digit): totals over the waves, each wave's base inside the digit, local start of the digit
+    const uint32_t c0 = wave_run[0][tid], c1 = wave_run[1][tid], c2 = wave_run[2][tid], c3 = wave_run[3][tid];
     uint32_t tot;
-    lstart[tid] = block_excl_scan_u32(digit_run[tid], &tot, lds4);
+    lstart[tid] = block_excl_scan_u32(c0 + c1 + c2 + c3, &tot, lds4);
+    wave_run[0][tid] = 0;
+    wave_run[1][tid] = c0;
+    wave_run[2][tid] = c0 + c1;
+    wave_run[3][tid] = c0 + c1 + c2;
   }
   __syncthreads();
 #pragma unroll
-  for (int s = 0; s < GSR_RADIX_SUBTILES; s++) {
-    const uint32_t li = (uint32_t)s * 256 + tid;
+  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++) {
+    const uint32_t li = wbase + (uint32_t)s * 64 + lane;
     if (li < count) {
-      const uint32_t lp = lstart[rk[s] >> 16] + (rk[s] & 0xFFFFu);
+      const uint32_t d = rk[s] >> 16;
+      const uint32_t lp = lstart[d] + my_run[d] + (rk[s] & 0xFFFFu);
       lkeys[lp] = key[s];
       lvals[lp] = val[s];
     }
