@@ -19,7 +19,7 @@ void gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const 
                                const GsrGeomLayout&, const float4*, const gsr_grads*, hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
 void gsr_launch_emit(int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, hipStream_t);
-void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
+void gsr_launch_finalize(uint32_t, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
                            float*, float*, uint32_t*, hipStream_t);
@@ -142,6 +142,10 @@ static int tile_bits(int tiles) {
 }
 // which ping-pong buffer holds the tile-sorted (key, slot) arrays: one swap per 8-bit pass
 static int tile_sort_result_buffer(int tiles) { return ((tile_bits(tiles) + GSR_RADIX_BITS - 1) / GSR_RADIX_BITS) & 1; }
+// the Gaussian-id list rides through the tile sort as a second payload, ping-ponging gauss_of_slot <-> point_list
+static size_t point_list_offset(const GsrBinLayout& BL, int tiles) {
+  return tile_sort_result_buffer(tiles) ? BL.point_list : BL.gauss_of_slot;
+}
 
 static int validate(const gsr_settings* s, const gsr_gaussians* g) {
   if (!s || !g) { gsr_set_error("null settings/gaussians"); return GSR_ERR_INVALID_ARGUMENT; }
@@ -296,15 +300,15 @@ int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geom
     if ((rc = debug_sync(s, st, "emit instances"))) return rc;
     const int where = gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a),
                                            (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.val_b),
-                                           /*vals_iota=*/true, R, tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st);
+                                           /*vals_iota=*/true, R, tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st,
+                                           (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(bin + BL.point_list));
     if (where != tile_sort_result_buffer(tiles)) { gsr_set_error("internal: tile sort buffer parity"); return GSR_ERR_HIP; }
     if ((rc = debug_sync(s, st, "tile sort"))) return rc;
     const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
-    const uint32_t* vs = (const uint32_t*)(bin + (where ? BL.val_b : BL.val_a));
-    gsr_launch_finalize((uint32_t)R, ks, vs, bin, BL, st);
+    gsr_launch_finalize((uint32_t)R, ks, bin, BL, st);
     if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
   }
-  gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + BL.point_list),
+  gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                         (const float4*)(geom + GL.rec), out_color, out_invdepth, (float*)(img + IL.final_T),
                         (uint32_t*)(img + IL.n_contrib), st);
   if ((rc = debug_sync(s, st, "render forward"))) return rc;
@@ -339,7 +343,7 @@ int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* r
   const char* img = (const char*)image_state;
   float4* igrad = (float4*)scratch;
   if (R > 0) {
-    gsr_launch_render_bwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + BL.point_list),
+    gsr_launch_render_bwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                           (const float4*)(geom + GL.rec), (const float*)(img + IL.final_T),
                           (const uint32_t*)(img + IL.n_contrib), dL_dcolor, dL_dinvdepth,
                           (const uint32_t*)(bin + (tile_sort_result_buffer(tiles) ? BL.val_b : BL.val_a)), igrad, st);
@@ -379,7 +383,7 @@ int gsr_debug_binning_views(const void* binning_state, int32_t W, int32_t H, int
   const size_t tiles = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * (size_t)((H + GSR_TILE - 1) / GSR_TILE);
   const GsrBinLayout BL = gsr_bin_layout((size_t)R, tiles);
   const char* bin = (const char*)binning_state;
-  if (point_list) *point_list = (const uint32_t*)(bin + BL.point_list);
+  if (point_list) *point_list = (const uint32_t*)(bin + point_list_offset(BL, tiles));
   if (ranges) *ranges = (const uint32_t*)(bin + BL.ranges);
   return 0;
 }

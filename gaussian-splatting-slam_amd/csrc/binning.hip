@@ -68,16 +68,11 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
   }
 }
 
-// one thread per sorted instance position: tile ranges + Gaussian id list
+// one thread per sorted instance position: tile ranges (the Gaussian id list comes out of the tile sort itself)
 __global__ __launch_bounds__(256) void k_finalize_bins(uint32_t R, const uint32_t* __restrict__ tile_sorted,
-                                                       const uint32_t* __restrict__ slot_sorted,
-                                                       const uint32_t* __restrict__ gauss_of_slot,
-                                                       uint32_t* __restrict__ point_list,
                                                        uint2* __restrict__ ranges) {
   const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
   if (pos >= R) return;
-  const uint32_t e = slot_sorted[pos];
-  point_list[pos] = gauss_of_slot[e];
   const uint32_t t = tile_sorted[pos];
   if (pos == 0) {
     ranges[t].x = 0;
@@ -99,8 +94,7 @@ void gsr_launch_emit(int P, int grid_x, const char* geom, const GsrGeomLayout& G
              (const float4*)(geom + GL.rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start));
 }
 
-void gsr_launch_finalize(uint32_t R, const uint32_t* tile_sorted, const uint32_t* slot_sorted, char* bin,
-                         const GsrBinLayout& BL, hipStream_t st) {
-  GSR_LAUNCH("finalize_bins", k_finalize_bins, dim3((R + 255) / 256), dim3(256), 0, st, R, tile_sorted, slot_sorted,
-             (const uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(bin + BL.point_list), (uint2*)(bin + BL.ranges));
+void gsr_launch_finalize(uint32_t R, const uint32_t* tile_sorted, char* bin, const GsrBinLayout& BL, hipStream_t st) {
+  GSR_LAUNCH("finalize_bins", k_finalize_bins, dim3((R + 255) / 256), dim3(256), 0, st, R, tile_sorted,
+             (uint2*)(bin + BL.ranges));
 }

@@ -47,8 +47,8 @@ struct GsrGeomLayout {
 struct GsrBinLayout {
   size_t key_a, key_b;   // u32[R] tile ids (ping-pong)
   size_t val_a, val_b;   // u32[R] emission slots (ping-pong); the sorted one (slot of each position) is kept for the backward
-  size_t gauss_of_slot;  // u32[R]
-  size_t point_list;     // u32[R] Gaussian ids sorted by (tile, depth, id)
+  size_t gauss_of_slot;  // u32[R] Gaussian id of each emission slot; second payload of the tile sort, ping-pongs with
+  size_t point_list;     // u32[R] -> Gaussian ids sorted by (tile, depth, id) end up in ONE of the two (pass parity)
   size_t ranges;         // uint2[tiles]
   size_t scan_tmp;
   size_t radix_tmp;
@@ -156,8 +156,9 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
                   uint32_t* tmp, hipStream_t st);
 // Stable LSD radix sort of (key,value) pairs on key bits [0, bits).  vals_in == nullptr means value = index.
 // Buffers ping-pong between (k0,v0) and (k1,v1); returns 0 if the result is in (k0,v0), 1 if in (k1,v1).
+// w0 / w1 (both or neither): a second 32-bit payload, input in w0, ping-ponging with w1 like the values.
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
-                         int bits, uint32_t* tmp, hipStream_t st);
+                         int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0 = nullptr, uint32_t* w1 = nullptr);
 
 // -------------------------------------------------------------------------------------------------
 // device helpers

@@ -195,9 +195,14 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ ta
 // Stable: equal digits keep (wave, sub-tile, lane) = original order.
 #define GSR_RADIX_WAVE_KEYS (GSR_RADIX_CHUNK / 4)
 #define GSR_RADIX_WAVE_TILES (GSR_RADIX_WAVE_KEYS / 64)
+// DUAL: a second 32-bit payload rides along (the tile sort carries the Gaussian id next to the emission slot, so no
+// gather by slot is needed afterwards).
+template <bool DUAL>
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                        const uint32_t* __restrict__ vals_in,
+                                                       const uint32_t* __restrict__ vals2_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                       uint32_t* __restrict__ vals2_out,
                                                        const uint32_t* __restrict__ table_excl,
                                                        const uint32_t* __restrict__ totals, size_t n, int shift,
                                                        uint32_t mask, uint32_t nblk) {
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
   __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
   __shared__ uint32_t lkeys[GSR_RADIX_CHUNK];
   __shared__ uint32_t lvals[GSR_RADIX_CHUNK];
+  __shared__ uint32_t lvals2[DUAL ? GSR_RADIX_CHUNK : 1];
   __shared__ uint32_t lds4[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   {
@@ -222,12 +228,14 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
   const uint32_t wbase = (uint32_t)w * GSR_RADIX_WAVE_KEYS;
   uint32_t* my_run = wave_run[w];
   uint32_t key[GSR_RADIX_WAVE_TILES], val[GSR_RADIX_WAVE_TILES], rk[GSR_RADIX_WAVE_TILES];   // rk = digit << 16 | rank in (wave, digit)
+  uint32_t val2[DUAL ? GSR_RADIX_WAVE_TILES : 1];
 #pragma unroll
   for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++) {
     const uint32_t li = wbase + (uint32_t)s * 64 + lane;
     const bool active = li < count;
     key[s] = active ? keys_in[base + li] : 0u;
     val[s] = active ? (vals_in ? vals_in[base + li] : (uint32_t)(base + li)) : 0u;
+    if (DUAL) val2[s] = active ? vals2_in[base + li] : 0u;
   }
 #pragma unroll
   for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++) {
@@ -269,6 +277,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
       const uint32_t lp = lstart[d] + my_run[d] + (rk[s] & 0xFFFFu);
       lkeys[lp] = key[s];
       lvals[lp] = val[s];
+      if (DUAL) lvals2[lp] = val2[s];
     }
   }
   __syncthreads();
@@ -278,15 +287,17 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     const uint32_t g = gbase[d] + (i - lstart[d]);
     keys_out[g] = k;
     vals_out[g] = lvals[i];
+    if (DUAL) vals2_out[g] = lvals2[i];
   }
 }
 
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
-                         int bits, uint32_t* tmp, hipStream_t st) {
+                         int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0, uint32_t* w1) {
   if (n == 0 || bits <= 0) return 0;
   const uint32_t nblk = (uint32_t)gsr_radix_blocks(n);
   uint32_t* table = tmp;
   uint32_t* totals = tmp + (size_t)GSR_RADIX_SIZE * nblk;     // sized by gsr_radix_tmp_elems: 256 * (nblk + 1)
+  const bool dual = w0 != nullptr && w1 != nullptr;
   int cur = 0;
   for (int shift = 0; shift < bits; shift += GSR_RADIX_BITS) {
     const int nb = (bits - shift) < GSR_RADIX_BITS ? (bits - shift) : GSR_RADIX_BITS;
@@ -299,8 +310,14 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
     GSR_LAUNCH("radix_hist", k_radix_hist, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, table, n, shift, mask,
                nblk);
     GSR_LAUNCH("radix_rowscan", k_radix_rowscan, dim3(GSR_RADIX_SIZE), dim3(256), 0, st, table, totals, nblk);
-    GSR_LAUNCH("radix_scatter", k_radix_scatter, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin, ko, vo,
-               (const uint32_t*)table, (const uint32_t*)totals, n, shift, mask, nblk);
+    if (dual)
+      GSR_LAUNCH("radix_scatter", k_radix_scatter<true>, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,
+                 (const uint32_t*)(cur ? w1 : w0), ko, vo, cur ? w0 : w1, (const uint32_t*)table,
+                 (const uint32_t*)totals, n, shift, mask, nblk);
+    else
+      GSR_LAUNCH("radix_scatter", k_radix_scatter<false>, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,
+                 (const uint32_t*)nullptr, ko, vo, (uint32_t*)nullptr, (const uint32_t*)table, (const uint32_t*)totals, n,
+                 shift, mask, nblk);
     cur ^= 1;
   }
   return cur;
