@@ -17,9 +17,8 @@
 #define EMIT_WINDOW 4096
 __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ offsets_incl,
-                                                        const uint32_t* __restrict__ tiles_touched,
-                                                        const ushort4* __restrict__ rect,
-                                                        const float4* __restrict__ rec, uint32_t* __restrict__ tile_key,
+                                                        const float4* __restrict__ bin_rec,
+                                                        uint32_t* __restrict__ tile_key,
                                                         uint32_t* __restrict__ gauss_of_slot,
                                                         uint32_t* __restrict__ slot_start) {
   __shared__ uint32_t lkey[EMIT_WINDOW], lgid[EMIT_WINDOW];
@@ -31,19 +30,23 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
   const bool staged = count <= EMIT_WINDOW;
   if (j < P) {
     const uint32_t g = order[j];
-    const uint32_t n = tiles_touched[g];
+    const uint32_t incl = offsets_incl[j];
+    const uint32_t n = incl - (j == 0 ? 0u : offsets_incl[j - 1]);   // = tiles_touched[g], without a gather
     if (n != 0) {  // culled Gaussians sort to the end (key 0xFFFFFFFF) and emit nothing
-      uint32_t off = offsets_incl[j] - n;
+      uint32_t off = incl - n;
       slot_start[g] = off;
-      const ushort4 r = rect[g];
-      // same inputs (the stored record) and the same compiled row-interval routine as k_preprocess_fwd -> exactly n tiles
-      const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1];
+      // same inputs (bit copies of the stored record fields) and the same compiled row-interval routine as
+      // k_preprocess_fwd -> exactly n tiles
+      const float4 r0 = bin_rec[2 * (size_t)g], r1 = bin_rec[2 * (size_t)g + 1];
+      const uint32_t rlo = __float_as_uint(r1.z), rhi = __float_as_uint(r1.w);
+      const ushort4 r = make_ushort4((unsigned short)(rlo & 0xFFFFu), (unsigned short)(rlo >> 16),
+                                     (unsigned short)(rhi & 0xFFFFu), (unsigned short)(rhi >> 16));
       const uint32_t end = off + n;
       uint32_t* kdst = staged ? lkey : tile_key;
       uint32_t* gdst = staged ? lgid : gauss_of_slot;
       const uint32_t bias = staged ? slot0 : 0u;
       for (int y = r.y; y < r.w; y++) {
-        const uint32_t iv = gsr_row_interval(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z, y, r.x, r.z);
+        const uint32_t iv = gsr_row_interval(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, y, r.x, r.z);
         const int lo = (int)(iv & 0xFFFFu), hi = (int)(iv >> 16);
         for (int x = lo; x < hi && off < end; x++) {
           kdst[off - bias] = (uint32_t)(y * grid_x + x);
@@ -90,8 +93,7 @@ void gsr_launch_emit(int P, int grid_x, const char* geom, const GsrGeomLayout& G
                      hipStream_t st) {
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
              (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
-             (const uint32_t*)(geom + GL.tiles_touched), (const ushort4*)(geom + GL.rect),
-             (const float4*)(geom + GL.rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start));
+             (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start));
 }
 
 void gsr_launch_finalize(uint32_t R, const uint32_t* tile_sorted, char* bin, const GsrBinLayout& BL, hipStream_t st) {

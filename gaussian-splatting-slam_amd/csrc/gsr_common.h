@@ -35,6 +35,8 @@ struct GsrGeomLayout {
   size_t val_tmp;        // u32[P]   sort ping-pong B
   size_t tiles_touched;  // u32[P]
   size_t rect;           // ushort4[P] tile rect (min.x, min.y, max.x, max.y)
+  size_t bin_rec;        // float4[2P] everything the emit pass needs of a Gaussian in ONE 32-B piece:
+                         //            (mx, my, A', B') (C', pmin', rect.xy | rect.zw as two u32)
   size_t offsets;        // u32[P]   inclusive scan of tiles_touched in depth order
   size_t slot_start;     // u32[P]   first emission slot of Gaussian g
   size_t clamped;        // u8[P]    bit c set: colour channel c clamped at 0
@@ -98,6 +100,7 @@ static inline GsrGeomLayout gsr_geom_layout(size_t P) {
   L.val_tmp = o;       o += gsr_align(P * 4);
   L.tiles_touched = o; o += gsr_align(P * 4);
   L.rect = o;          o += gsr_align(P * 8);
+  L.bin_rec = o;       o += gsr_align(P * 32);
   L.offsets = o;       o += gsr_align(P * 4);
   L.slot_start = o;    o += gsr_align(P * 4);
   L.clamped = o;       o += gsr_align(P);

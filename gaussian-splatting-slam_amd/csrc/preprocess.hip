@@ -114,40 +114,48 @@ __device__ __forceinline__ float sh_coef(const float* dc, const float* shs, int 
 // degree 3).  Reading it as per-thread 12-B pieces at a 192-B stride costs 48 uncoalesced dword loads per lane; instead
 // the span is copied with flat 16-B/lane loads into LDS rows of ODD stride Sp = S|1 (a thread walking its own row then
 // hits 32 distinct banks across the wave), and the gradient rows go back to HBM the same way.
+// (row, column) of flat element e = 4 i is carried incrementally from trip to trip (i advances by 256, e by 1024): one
+// runtime division per thread instead of one per 16-B piece.
 __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int nflt, int S, int Sp, float* lds) {
   const int n4 = nflt >> 2;
+  const int dr = 1024 / S, dc = 1024 - dr * S;                 // (row, column) advance per trip
+  int r = (threadIdx.x * 4) / S, c = threadIdx.x * 4 - r * S;
   for (int i = threadIdx.x; i < n4; i += 256) {
     const float4 v = gsr_ld_stream4(reinterpret_cast<const float4*>(src) + i);   // SH rows pass through once per kernel
-    const int e = i * 4;
-    int r = e / S, c = e - r * S;
     const float vv[4] = {v.x, v.y, v.z, v.w};
+    int rr = r, cc = c;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      lds[r * Sp + c] = vv[k];
-      if (++c == S) { c = 0; r++; }
+      lds[rr * Sp + cc] = vv[k];
+      if (++cc == S) { cc = 0; rr++; }
     }
+    r += dr; c += dc;
+    if (c >= S) { c -= S; r++; }
   }
   for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {
-    const int r = e / S, c = e - r * S;
-    lds[r * Sp + c] = src[e];
+    const int r2 = e / S, c2 = e - r2 * S;
+    lds[r2 * Sp + c2] = src[e];
   }
 }
 __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, int nflt, int S, int Sp, const float* lds) {
   const int n4 = nflt >> 2;
+  const int dr = 1024 / S, dc = 1024 - dr * S;
+  int r = (threadIdx.x * 4) / S, c = threadIdx.x * 4 - r * S;
   for (int i = threadIdx.x; i < n4; i += 256) {
-    const int e = i * 4;
-    int r = e / S, c = e - r * S;
+    int rr = r, cc = c;
     float vv[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      vv[k] = lds[r * Sp + c];
-      if (++c == S) { c = 0; r++; }
+      vv[k] = lds[rr * Sp + cc];
+      if (++cc == S) { cc = 0; rr++; }
     }
     gsr_st_stream4(reinterpret_cast<float4*>(dst) + i, make_float4(vv[0], vv[1], vv[2], vv[3]));
+    r += dr; c += dc;
+    if (c >= S) { c -= S; r++; }
   }
   for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {
-    const int r = e / S, c = e - r * S;
-    dst[e] = lds[r * Sp + c];
+    const int r2 = e / S, c2 = e - r2 * S;
+    dst[e] = lds[r2 * Sp + c2];
   }
 }
 // coefficient k of channel c of this thread's Gaussian, staged variant
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy, int prefiltered, int antialiasing,
     int defer_color, int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
     uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
+    float4* __restrict__ bin_rec,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -327,6 +336,10 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
         rec[3 * (size_t)idx + 1] = make_float4(sC, op, spmin, rgb[0]);
         rec[3 * (size_t)idx + 2] = make_float4(rgb[1], rgb[2], 1.0f / t[2], t[2]);
         rect[idx] = make_ushort4((unsigned short)cx0, (unsigned short)cy0, (unsigned short)cx1, (unsigned short)cy1);
+        // the emit pass walks the Gaussians in DEPTH order: one 32-B gather per Gaussian instead of three (record, rect, count)
+        bin_rec[2 * (size_t)idx + 0] = make_float4(px, py, sA, sB);
+        bin_rec[2 * (size_t)idx + 1] = make_float4(sC, spmin, __uint_as_float((uint32_t)cx0 | ((uint32_t)cy0 << 16)),
+                                                   __uint_as_float((uint32_t)cx1 | ((uint32_t)cy1 << 16)));
         clamped[idx] = cl;
         out_radius = (int32_t)radius;        // radii / visibility are the published ones (3-sigma rectangle non-empty)
         out_tiles = (uint32_t)kept;
@@ -795,7 +808,7 @@ void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, in
       g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width, s->image_height,  \
       s->tanfovx, s->tanfovy, s->prefiltered, s->antialiasing, (int)defer_color, radii, (float4*)(geom + L.rec),     \
       (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles_touched),              \
-      (ushort4*)(geom + L.rect), (uint8_t*)(geom + L.clamped), (uint32_t*)(geom + L.meta)
+      (ushort4*)(geom + L.rect), (float4*)(geom + L.bin_rec), (uint8_t*)(geom + L.clamped), (uint32_t*)(geom + L.meta)
   if (stage)
     GSR_LAUNCH("preprocess_fwd", k_preprocess_fwd<true>, dim3((P + 255) / 256), dim3(256), lds, st, GSR_PRE_FWD_ARGS);
   else
