@@ -18,7 +18,7 @@ void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const Gs
 void gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
                                const GsrGeomLayout&, const float4*, const gsr_grads*, hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
-void gsr_launch_emit(int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, hipStream_t);
+void gsr_launch_emit(int, int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_finalize(uint32_t, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
@@ -294,9 +294,10 @@ int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geom
   char* geom = (char*)geometry_state;
   char* bin = (char*)binning_state;
   char* img = (char*)image_state;
-  if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
-  if (R > 0) {
-    gsr_launch_emit(g->P, gx, geom, GL, bin, BL, st);
+  if (R == 0) {   // nothing to emit: every tile range is empty (otherwise the emit kernel clears them on its way)
+    if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
+  } else {
+    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, st);
     if ((rc = debug_sync(s, st, "emit instances"))) return rc;
     const int where = gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a),
                                            (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.val_b),

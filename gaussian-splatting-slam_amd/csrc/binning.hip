@@ -20,8 +20,11 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
                                                         const float4* __restrict__ bin_rec,
                                                         uint32_t* __restrict__ tile_key,
                                                         uint32_t* __restrict__ gauss_of_slot,
-                                                        uint32_t* __restrict__ slot_start) {
+                                                        uint32_t* __restrict__ slot_start, int tiles,
+                                                        uint2* __restrict__ ranges) {
   __shared__ uint32_t lkey[EMIT_WINDOW], lgid[EMIT_WINDOW];
+  // the tile ranges are filled in after the tile sort (k_finalize_bins); tiles without instances keep this (0, 0)
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);
   const int j0 = blockIdx.x * 256;
   const int j = j0 + threadIdx.x;
   const int jlast = min(j0 + 255, P - 1);
@@ -89,11 +92,12 @@ __global__ __launch_bounds__(256) void k_finalize_bins(uint32_t R, const uint32_
   if (pos == R - 1) ranges[t].y = R;
 }
 
-void gsr_launch_emit(int P, int grid_x, const char* geom, const GsrGeomLayout& GL, char* bin, const GsrBinLayout& BL,
-                     hipStream_t st) {
+void gsr_launch_emit(int P, int grid_x, int tiles, const char* geom, const GsrGeomLayout& GL, char* bin,
+                     const GsrBinLayout& BL, hipStream_t st) {
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
              (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
-             (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start));
+             (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start), tiles,
+             (uint2*)(bin + BL.ranges));
 }
 
 void gsr_launch_finalize(uint32_t R, const uint32_t* tile_sorted, char* bin, const GsrBinLayout& BL, hipStream_t st) {

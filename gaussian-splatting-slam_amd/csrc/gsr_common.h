@@ -197,16 +197,19 @@ __device__ __noinline__ uint32_t gsr_row_interval(float mx, float my, float As, 
                                                   int cx0, int cx1) {
   const float A = As * (-2.0f / GSR_LOG2E), B = Bs * (-1.0f / GSR_LOG2E), C = Cs * (-2.0f / GSR_LOG2E);
   const float q = pmins * (-2.0f / GSR_LOG2E);
+  // (hardware rcp / sqrt, 1 ulp: every use below carries a slack orders of magnitude larger, and both callers run this one
+  // compiled body, so count and emission still agree bit for bit)
   const float det = A * C - B * B;
-  const float hy = sqrtf(fmaxf(0.f, q * A / det)) * 1.0001f + 0.01f;       // ellipse half-height (+ slack)
+  const float rdet = __builtin_amdgcn_rcpf(det), rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+  const float hy = __builtin_amdgcn_sqrtf(fmaxf(0.f, q * A * rdet)) * 1.0001f + 0.01f;   // ellipse half-height (+ slack)
   const float yl = (float)(ty * GSR_TILE) - my, yh = yl + (float)(GSR_TILE - 1);
   const float bl = fmaxf(yl, -hy), bh = fminf(yh, hy);
   if (bl > bh) return 0u;                                                   // band misses the ellipse
-  const float yr = -B * sqrtf(fmaxf(0.f, q / (C * det)));                  // height of the right-most point (left-most: -yr)
+  const float yr = -B * __builtin_amdgcn_sqrtf(fmaxf(0.f, q * rC * rdet));  // height of the right-most point (left-most: -yr)
   const float y1 = fminf(bh, fmaxf(bl, yr)), y2 = fminf(bh, fmaxf(bl, -yr));
   const float qa = q * 1.0002f + 0.002f;                                   // conservative slack >> fp32 error
-  const float xhi = (-B * y1 + sqrtf(fmaxf(0.f, A * qa - det * y1 * y1))) / A + 0.01f;
-  const float xlo = (-B * y2 - sqrtf(fmaxf(0.f, A * qa - det * y2 * y2))) / A - 0.01f;
+  const float xhi = (-B * y1 + __builtin_amdgcn_sqrtf(fmaxf(0.f, A * qa - det * y1 * y1))) * rA + 0.01f;
+  const float xlo = (-B * y2 - __builtin_amdgcn_sqrtf(fmaxf(0.f, A * qa - det * y2 * y2))) * rA - 0.01f;
   // tile column t holds pixel centres 16t .. 16t+15 (relative to the mean: subtract mx)
   const float lim = 1.0e9f;
   int lo = (int)ceilf(fmaxf(-lim, (mx + xlo - (float)(GSR_TILE - 1)) / GSR_TILE));

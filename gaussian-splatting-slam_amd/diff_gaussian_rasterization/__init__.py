@@ -117,7 +117,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-            radii = torch.zeros(P, dtype=torch.int32, device=dev)
+            radii = torch.empty(P, dtype=torch.int32, device=dev)     # every entry is written by the projection kernel
             s, keep = _settings_struct(rs, dev)
             g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
             geom = torch.empty(lib.gsr_geometry_state_bytes(P), dtype=torch.uint8, device=dev)

@@ -61,14 +61,16 @@ class MiniCam:
         self.FoVx = float(fovx)
         self.znear = znear
         self.zfar = zfar
-        self.world_view_transform = world_view_transform
-        self.full_proj_transform = full_proj_transform
+        # contiguous once, here: the rasterizer wrapper hands raw pointers to the library and would otherwise copy the
+        # (transposed-view) matrices on every call
+        self.world_view_transform = world_view_transform.contiguous()
+        self.full_proj_transform = full_proj_transform.contiguous()
         self.camera_center = torch.inverse(world_view_transform.float().cpu())[3][:3].to(world_view_transform.device)
         self.image_name = image_name
 
     def to(self, device):
-        self.world_view_transform = self.world_view_transform.to(device)
-        self.full_proj_transform = self.full_proj_transform.to(device)
+        self.world_view_transform = self.world_view_transform.to(device).contiguous()
+        self.full_proj_transform = self.full_proj_transform.to(device).contiguous()
         self.camera_center = self.camera_center.to(device)
         return self
 
