@@ -209,9 +209,8 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
   __shared__ uint32_t wave_run[4][GSR_RADIX_SIZE];  // phase 1: keys of (wave, digit) seen so far; phase 2: the wave's base
   __shared__ uint32_t lstart[GSR_RADIX_SIZE];       // first local (sorted) position of each digit
   __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
-  __shared__ uint32_t lkeys[GSR_RADIX_CHUNK];
-  __shared__ uint32_t lvals[GSR_RADIX_CHUNK];
-  __shared__ uint32_t lvals2[DUAL ? GSR_RADIX_CHUNK : 1];
+  __shared__ uint32_t lbuf[GSR_RADIX_CHUNK];        // ONE staging buffer, reused for keys, values (and the second payload):
+                                                    // 21 KB of LDS per workgroup instead of 36 / 52 -> 7 workgroups per CU
   __shared__ uint32_t lds4[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   {
@@ -269,25 +268,51 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     wave_run[3][tid] = c0 + c1 + c2;
   }
   __syncthreads();
+  // local sorted position of each of this thread's keys
 #pragma unroll
   for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++) {
-    const uint32_t li = wbase + (uint32_t)s * 64 + lane;
-    if (li < count) {
-      const uint32_t d = rk[s] >> 16;
-      const uint32_t lp = lstart[d] + my_run[d] + (rk[s] & 0xFFFFu);
-      lkeys[lp] = key[s];
-      lvals[lp] = val[s];
-      if (DUAL) lvals2[lp] = val2[s];
+    const uint32_t d = rk[s] >> 16;
+    rk[s] = lstart[d] + my_run[d] + (rk[s] & 0xFFFFu);
+  }
+  // round 1: keys through LDS; each thread also learns the global position of the sorted positions it streams out
+  uint32_t gpos[GSR_RADIX_SUBTILES];
+#pragma unroll
+  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++)
+    if (wbase + (uint32_t)s * 64 + lane < count) lbuf[rk[s]] = key[s];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < GSR_RADIX_SUBTILES; k++) {
+    const uint32_t i = (uint32_t)k * 256 + tid;
+    gpos[k] = 0;
+    if (i < count) {
+      const uint32_t kk = lbuf[i];
+      const uint32_t d = (kk >> shift) & mask;
+      gpos[k] = gbase[d] + (i - lstart[d]);
+      keys_out[gpos[k]] = kk;
     }
   }
   __syncthreads();
-  for (uint32_t i = tid; i < count; i += 256) {
-    const uint32_t k = lkeys[i];
-    const uint32_t d = (k >> shift) & mask;
-    const uint32_t g = gbase[d] + (i - lstart[d]);
-    keys_out[g] = k;
-    vals_out[g] = lvals[i];
-    if (DUAL) vals2_out[g] = lvals2[i];
+  // round 2: values
+#pragma unroll
+  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++)
+    if (wbase + (uint32_t)s * 64 + lane < count) lbuf[rk[s]] = val[s];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < GSR_RADIX_SUBTILES; k++) {
+    const uint32_t i = (uint32_t)k * 256 + tid;
+    if (i < count) vals_out[gpos[k]] = lbuf[i];
+  }
+  if (DUAL) {   // round 3: the second payload
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++)
+      if (wbase + (uint32_t)s * 64 + lane < count) lbuf[rk[s]] = val2[s];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GSR_RADIX_SUBTILES; k++) {
+      const uint32_t i = (uint32_t)k * 256 + tid;
+      if (i < count) vals2_out[gpos[k]] = lbuf[i];
+    }
   }
 }
 
