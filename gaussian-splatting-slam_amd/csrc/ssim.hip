@@ -44,16 +44,21 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
   const size_t plane = (size_t)blockIdx.z * H * W;
-  for (int i = tid; i < SH * SH; i += 256) {
-    const int r = i / SH, c = i - r * SH;
-    const int gy = y0 + r - SR, gx = x0 + c - SR;
-    float a = 0.f, b = 0.f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      a = img1[plane + (size_t)gy * W + gx];
-      b = img2[plane + (size_t)gy * W + gx];
+  // halo load; (row, column) of flat index i is carried from trip to trip (i += 256 = 6 rows + 4 columns at SH = 42)
+  {
+    int r = tid / SH, c = tid - r * SH;
+    for (int i = tid; i < SH * SH; i += 256) {
+      const int gy = y0 + r - SR, gx = x0 + c - SR;
+      float a = 0.f, b = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        a = img1[plane + (size_t)gy * W + gx];
+        b = img2[plane + (size_t)gy * W + gx];
+      }
+      sx[r][c] = a;
+      sy[r][c] = b;
+      r += 256 / SH; c += 256 % SH;
+      if (c >= SH) { c -= SH; r++; }
     }
-    sx[r][c] = a;
-    sy[r][c] = b;
   }
   __syncthreads();
   // horizontal pass: SH rows x ST columns, FOUR adjacent columns per thread: the 14 taps they share are read from LDS once
@@ -100,7 +105,9 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
       const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
       const float A = 2.f * mu12 + C1, B = 2.f * sigma12 + C2;
       const float Cc = mu1_sq + mu2_sq + C1, D = sigma1_sq + sigma2_sq + C2;
-      const float inv = 1.0f / (Cc * D);
+      // (v_rcp_f32, 1 ulp: three IEEE divisions per pixel-channel were ~10 % of this kernel's instructions)
+      const float rCc = __builtin_amdgcn_rcpf(Cc), rD = __builtin_amdgcn_rcpf(D);
+      const float inv = rCc * rD;
       const float m = A * B * inv;
       const size_t o = plane + (size_t)gy * W + gx;
       if (ssim_map) ssim_map[o] = m;
@@ -108,8 +115,8 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
       acc_l1 += fabsf(sx[r + SR][c + SR] - sy[r + SR][c + SR]);
       if (dm_dmu1) {
         // partials holding E[xx], E[yy], E[xy] fixed (sigma's depend on mu1 through -mu1^2, -mu1*mu2)
-        dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - m * 2.f * mu1 / Cc + m * 2.f * mu1 / D;
-        dm_dsigma1_sq[o] = -m / D;
+        dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - m * 2.f * mu1 * rCc + m * 2.f * mu1 * rD;
+        dm_dsigma1_sq[o] = -m * rD;
         dm_dsigma12[o] = 2.f * A * inv;
       }
     }
@@ -154,8 +161,11 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, SsimWindow win, 
     g_const *= u;
     g_l1 *= u;
   }
+  int lr = tid / SH, lc = tid - lr * SH;             // (row, column) of the flat halo index, carried incrementally
   for (int i = tid; i < SH * SH; i += 256) {
-    const int r = i / SH, c = i - r * SH;
+    const int r = lr, c = lc;
+    lr += 256 / SH; lc += 256 % SH;
+    if (lc >= SH) { lc -= SH; lr++; }
     const int gy = y0 + r - SR, gx = x0 + c - SR;
     float a = 0.f, b = 0.f, d = 0.f;
     if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
