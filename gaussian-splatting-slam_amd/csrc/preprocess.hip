@@ -103,6 +103,31 @@ __device__ __forceinline__ void ewa_project(const float t[3], const PreView& v, 
   e.c0 = e.m1[0] * s1x + e.m1[1] * s1y + e.m1[2] * s1z;
 }
 
+// Scale / rotation / opacity of Gaussian idx as the rasterizer consumes them.  raw == 0: the arrays hold activated values
+// (the reference's call form).  raw != 0: they hold the model's RAW parameters and the activations of reference
+// scene/gaussian_model.py:38-46 are applied on load - exp, F.normalize (x / max(|x|, 1e-12)), sigmoid - so the model needs no
+// activation kernels of its own; the backward then returns gradients w.r.t. the raw parameters (chain rule in
+// k_preprocess_bwd).  qden = max(|q_raw|, 1e-12) (1 when not raw).
+__device__ __forceinline__ void load_scale_rot(const float* __restrict__ scales, const float* __restrict__ rotations,
+                                               size_t idx, int raw, float* s3, float* q4, float& qden) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) s3[j] = scales[3 * idx + j];
+#pragma unroll
+  for (int j = 0; j < 4; j++) q4[j] = rotations[4 * idx + j];
+  qden = 1.0f;
+  if (raw) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) s3[j] = expf(s3[j]);
+    qden = fmaxf(sqrtf(q4[0] * q4[0] + q4[1] * q4[1] + q4[2] * q4[2] + q4[3] * q4[3]), 1e-12f);
+#pragma unroll
+    for (int j = 0; j < 4; j++) q4[j] = q4[j] / qden;
+  }
+}
+__device__ __forceinline__ float load_opacity(const float* __restrict__ opacities, size_t idx, int raw) {
+  const float x = opacities[idx];
+  return raw ? 1.0f / (1.0f + expf(-x)) : x;
+}
+
 __device__ __forceinline__ float sh_coef(const float* dc, const float* shs, int stride, int idx, int k, int c) {
   // coefficient k of channel c of Gaussian idx; with `dc`, band 0 lives there and shs holds k-1
   if (dc) return (k == 0) ? dc[3 * (size_t)idx + c] : shs[((size_t)idx * stride + (k - 1)) * 3 + c];
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     float scale_modifier, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy, int prefiltered, int antialiasing,
-    int defer_color, int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
+    int defer_color, int raw_act, int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
     uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
     float4* __restrict__ bin_rec,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta) {
@@ -239,7 +264,9 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
 #pragma unroll
       for (int i = 0; i < 6; i++) cov6[i] = cov3D_precomp[6 * (size_t)idx + i];
     } else {
-      cov3d_from_sr(scales + 3 * (size_t)idx, rotations + 4 * (size_t)idx, scale_modifier, cov6, nullptr);
+      float s3[3], q4[4], qden;
+      load_scale_rot(scales, rotations, (size_t)idx, raw_act, s3, q4, qden);
+      cov3d_from_sr(s3, q4, scale_modifier, cov6, nullptr);
     }
     const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
     Ewa e;
@@ -297,7 +324,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
             if (rgb[ch] < 0.f) { cl |= (1u << ch); rgb[ch] = 0.f; }
           }
         }
-        const float op = opacities[idx] * h;
+        const float op = load_opacity(opacities, (size_t)idx, raw_act) * h;
         // conservative cut-off for the render kernels: alpha = op*exp(power) >= 1/255  <=>  power >= -ln(255 op);
         // the margin (>> fp32 error of power / exp) keeps the test a pure accelerator (exact test follows it)
         const float pmin = (op > 0.f) ? (-logf(255.0f * op) - 0.01f) : 1.0f;
@@ -449,7 +476,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     float scale_modifier, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
-    const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy, int antialiasing,
+    const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy, int antialiasing, int raw_act,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ slot_start, const float4* __restrict__ igrad, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_ddc, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
@@ -574,11 +601,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     // ---- covariance chain (A.7 i, ii) ----
     float cov6[6];
     float R[9];
+    float s3[3] = {0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, qden = 1.0f;
     if (cov3D_precomp) {
 #pragma unroll
       for (int i = 0; i < 6; i++) cov6[i] = cov3D_precomp[6 * (size_t)idx + i];
     } else {
-      cov3d_from_sr(scales + 3 * (size_t)idx, rotations + 4 * (size_t)idx, scale_modifier, cov6, R);
+      load_scale_rot(scales, rotations, (size_t)idx, raw_act, s3, q4, qden);
+      cov3d_from_sr(s3, q4, scale_modifier, cov6, R);
     }
     const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
     Ewa e;
@@ -596,7 +625,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float g_a = det2inv * (-c * c * gA + b * c * gB - b * b * gC);
     float g_c = det2inv * (-b * b * gA + a * b * gB - a * a * gC);
     float g_b = det2inv * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
-    const float opac = opacities[idx];
+    const float opac = load_opacity(opacities, (size_t)idx, raw_act);
     if (antialiasing) {
       const float det0 = e.a0 * e.c0 - b * b;
       const float f = det0 / det;
@@ -671,8 +700,6 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 
     // ---- Sigma -> scale, rotation (A.7 v) ----
     if (!cov3D_precomp) {
-      const float* s3 = scales + 3 * (size_t)idx;
-      const float* q4 = rotations + 4 * (size_t)idx;
       const float sp[3] = {scale_modifier * s3[0], scale_modifier * s3[1], scale_modifier * s3[2]};
       // G = full symmetric gradient matrix; dL/dL = 2 G L, L = R diag(sp)
       const float G[9] = {g_cov6[0],       0.5f * g_cov6[1], 0.5f * g_cov6[2], 0.5f * g_cov6[1], g_cov6[3],
@@ -698,7 +725,15 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
                         2.f * y * gR[8]);
       g_rot[3] = 2.f * (-2.f * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2.f * z * gR[4] + y * gR[5] + x * gR[6] +
                         y * gR[7]);
+      if (raw_act) {   // through exp and F.normalize (q4 is the unit quaternion, qden = max(|q_raw|, eps))
+#pragma unroll
+        for (int j = 0; j < 3; j++) g_scale[j] *= s3[j];
+        const float dot = qden > 1e-12f ? q4[0] * g_rot[0] + q4[1] * g_rot[1] + q4[2] * g_rot[2] + q4[3] * g_rot[3] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) g_rot[j] = (g_rot[j] - q4[j] * dot) / qden;
+      }
     }
+    if (raw_act) g_opac *= opac * (1.0f - opac);     // through sigmoid
   }
 
   // ---- write every output (zeros for culled Gaussians: no memset pass needed) ----
@@ -806,7 +841,8 @@ void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, in
 #define GSR_PRE_FWD_ARGS                                                                                              \
   P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations, \
       g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width, s->image_height,  \
-      s->tanfovx, s->tanfovy, s->prefiltered, s->antialiasing, (int)defer_color, radii, (float4*)(geom + L.rec),     \
+      s->tanfovx, s->tanfovy, s->prefiltered, s->antialiasing, (int)defer_color, (int)g->raw_activations, radii,    \
+      (float4*)(geom + L.rec),                                                                                       \
       (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles_touched),              \
       (ushort4*)(geom + L.rect), (float4*)(geom + L.bin_rec), (uint8_t*)(geom + L.clamped), (uint32_t*)(geom + L.meta)
   if (stage)
@@ -825,7 +861,7 @@ void gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, co
 #define GSR_PRE_BWD_ARGS                                                                                              \
   P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations, \
       g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width, s->image_height,  \
-      s->tanfovx, s->tanfovy, s->antialiasing, radii, (const uint8_t*)(geom + L.clamped),                             \
+      s->tanfovx, s->tanfovy, s->antialiasing, (int)g->raw_activations, radii, (const uint8_t*)(geom + L.clamped),     \
       (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), igrad, gr->dL_dmeans3D,      \
       gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities, gr->dL_dscales, gr->dL_drotations, \
       gr->dL_dcov3D

@@ -33,6 +33,7 @@ class gsr_gaussians(C.Structure):
         ("P", C.c_int32), ("sh_coeffs", C.c_int32),
         ("means3D", C.c_void_p), ("dc", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+        ("raw_activations", C.c_int32),
     ]
 
 
@@ -116,8 +117,8 @@ def lib():
             f = getattr(l, name)         # AttributeError if a declared symbol is not exported
             f.restype = res
             f.argtypes = args
-        if l.gsr_abi_version() != 1:
-            raise GsrError(f"libgsr_hip.so ABI {l.gsr_abi_version()} != 1")
+        if l.gsr_abi_version() != 2:
+            raise GsrError(f"libgsr_hip.so ABI {l.gsr_abi_version()} != 2")
         _lib = l
     return _lib
 

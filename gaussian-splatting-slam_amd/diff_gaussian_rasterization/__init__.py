@@ -82,12 +82,13 @@ def _settings_struct(rs: GaussianRasterizationSettings, device):
     return s, (bg, vm, pm, cp)   # keep the tensors alive
 
 
-def _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp):
+def _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, raw_activations=False):
     def p(t):
         return None if t is None else t.data_ptr()
     return _C.gsr_gaussians(
         int(P), int(sh.shape[1]) if sh is not None else 0,
-        p(means3D), p(dc), p(sh), p(colors_precomp), p(opacities), p(scales), p(rotations), p(cov3D_precomp))
+        p(means3D), p(dc), p(sh), p(colors_precomp), p(opacities), p(scales), p(rotations), p(cov3D_precomp),
+        1 if raw_activations else 0)
 
 
 def _stream():
@@ -100,8 +101,9 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                raster_settings):
+                raster_settings, raw_activations=False):
         lib = _C.lib()
+        raw_activations = bool(raw_activations) and cov3D_precomp is None
         if not means3D.is_cuda:
             raise _C.GsrError("GaussianRasterizer needs tensors on the HIP device (no CPU path)")
         dev = means3D.device
@@ -119,7 +121,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)     # every entry is written by the projection kernel
             s, keep = _settings_struct(rs, dev)
-            g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+            g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                              raw_activations)
             geom = torch.empty(lib.gsr_geometry_state_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(lib.gsr_image_state_bytes(W, H), dtype=torch.uint8, device=dev)
             global _sh_ready_event
@@ -146,6 +149,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
         last_call_stats["num_rendered"] = int(R)
         ctx.raster_settings = rs
+        ctx.raw_activations = raw_activations
         ctx.num_rendered = R
         ctx.has = (dc is not None, sh is not None, colors_precomp is not None, scales is not None,
                    cov3D_precomp is not None)
@@ -185,7 +189,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_cov = like(cov3D_precomp, P, 6)
             if P > 0:
                 s, keep = _settings_struct(rs, dev)
-                g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+                g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                  ctx.raw_activations)
                 scratch = torch.empty(lib.gsr_backward_scratch_bytes(P, R), dtype=torch.uint8, device=dev)
                 gr = _C.gsr_grads(*[None if t is None else t.data_ptr() for t in
                                     (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov)])
@@ -198,13 +203,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                         _dump("snapshot_bw.dump", rs, means3D, dc, sh, colors_precomp, opacities, scales, rotations,
                               cov3D_precomp, grad_color, grad_invdepth, radii)
                     raise
-        return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None)
+        return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, raw_activations=False):
     return _RasterizeGaussians.apply(means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, raw_activations)
 
 
 class GaussianRasterizer(nn.Module):
@@ -226,7 +231,10 @@ class GaussianRasterizer(nn.Module):
             return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, dc=None):
+                cov3D_precomp=None, dc=None, raw_activations=False):
+        """Arguments of the reference's call (gaussian_renderer/__init__.py:90-109).  `raw_activations=True` (an extension,
+        keyword only in spirit): `opacities`, `scales`, `rotations` are the model's RAW parameters; sigmoid / exp / normalize
+        are applied inside the projection kernel and the returned gradients are w.r.t. the raw parameters."""
         def none_if_empty(t):
             return None if (t is None or t.numel() == 0) else t
         shs, colors_precomp, dc = none_if_empty(shs), none_if_empty(colors_precomp), none_if_empty(dc)
@@ -240,7 +248,7 @@ class GaussianRasterizer(nn.Module):
                     ((scales is not None or rotations is not None) and cov3D_precomp is not None):
                 raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         return rasterize_gaussians(means3D, means2D, dc, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, self.raster_settings)
+                                   cov3D_precomp, self.raster_settings, raw_activations)
 
 
 from .sparse_adam import SparseGaussianAdam, FusedAdam  # noqa: E402,F401   (reference train.py:37-41)

@@ -52,11 +52,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     means2D = screenspace_points
 
     scales = rotations = cov3D_precomp = None
-    # A model that offers the fused activation op (scene_utils.model.GaussianModel.get_activated: one launch for exp /
-    # normalize / sigmoid) is asked for all three at once; any other model object goes through the reference's getters.
-    fused = getattr(pc, "get_activated", None)
-    if fused is not None and not pipe.compute_cov3D_python:
-        scales, rotations, opacity = fused()
+    # A model that hands out its RAW parameters (scene_utils.model.GaussianModel.get_raw_geometry) lets the rasterizer apply
+    # exp / normalize / sigmoid inside its projection kernel (and chain them in its backward): no activation kernels at all
+    # in the step.  Any other model object goes through the reference's getters.
+    raw = getattr(pc, "get_raw_geometry", None)
+    use_raw = raw is not None and not pipe.compute_cov3D_python
+    if use_raw:
+        scales, rotations, opacity = raw()
     else:
         opacity = pc.get_opacity
         if pipe.compute_cov3D_python:
@@ -83,11 +85,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if separate_sh:
         rendered_image, radii, depth_image = rasterizer(
             means3D=means3D, means2D=means2D, dc=dc, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_activations": True} if use_raw else {}))
     else:
         rendered_image, radii, depth_image = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_activations": True} if use_raw else {}))
 
     if use_trained_exp:
         exposure = pc.get_exposure_from_name(viewpoint_camera.image_name)

@@ -86,6 +86,12 @@ class GaussianModel:
     def get_opacity(self):
         return torch.sigmoid(self._opacity)
 
+    def get_raw_geometry(self):
+        """(_scaling, _rotation, _opacity): the raw parameters, for a rasterizer that applies the activations itself
+        (`GaussianRasterizer.forward(..., raw_activations=True)`); render() prefers this on the HIP device.  None-returning
+        on CPU tensors is not needed: render() is only ever called with device models."""
+        return self._scaling, self._rotation, self._opacity
+
     def get_activated(self):
         """(scaling, rotation, opacity) as get_scaling / get_rotation / get_opacity return them, through ONE fused HIP
         launch (and one in the backward) when the parameters live on the device; render() prefers this when the model

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 enum {
   GSR_OK = 0,
@@ -73,6 +73,11 @@ typedef struct gsr_gaussians {
   const float* scales;         /* [P,3] or NULL */
   const float* rotations;      /* [P,4] (w,x,y,z), used as given, or NULL */
   const float* cov3D_precomp;  /* [P,6] (xx,xy,xz,yy,yz,zz) or NULL */
+  int32_t raw_activations;     /* 0: opacities / scales / rotations are activated values (the reference's call form).
+                                * 1: they are the model's RAW parameters (scene/gaussian_model.py:55-57 _scaling, _rotation,
+                                *    _opacity): exp / normalize / sigmoid (:38-46) are applied on load, and gsr_backward returns
+                                *    the gradients w.r.t. the raw parameters - the model then needs no activation kernels in
+                                *    the training step.  Ignored for cov3D_precomp. */
 } gsr_gaussians;
 
 /* Gradients returned by the backward, in the order the reference's autograd Function returns them

@@ -50,9 +50,10 @@ def test_fused_activations_partial_gradients_and_degenerate_quaternion():
     assert torch.count_nonzero(a[0].grad) == 0 and torch.count_nonzero(a[2].grad) == 0
 
 
-def test_render_uses_fused_activations_with_same_result():
-    """render() asks a model that offers get_activated() for the fused triple; image and parameter gradients equal the
-    getter path's."""
+def test_render_raw_parameter_path_matches_getter_path():
+    """render() hands the RAW parameters of a model that offers get_raw_geometry() to the rasterizer
+    (`raw_activations=True`: exp / normalize / sigmoid inside the projection kernel, chained in its backward); image and
+    parameter gradients equal those of the reference's getter path (torch.exp / F.normalize / torch.sigmoid + autograd)."""
     from gaussian_renderer import PipelineParams, render
     from scene_utils.cameras import look_at_camera
     from scene_utils.model import GaussianModel
