@@ -2,15 +2,18 @@
 //
 // MI355X mapping: one 256-thread workgroup (4 wave64) per tile; wave w owns the 8x8 pixel quadrant w, lane l
 // the pixel (l&7, l>>3) of it, so a Gaussian that misses a quadrant is rejected for 64 pixels by ONE
-// wave-uniform ballot + branch.  Batches of 256 packed 48-B splat records are staged through LDS (one
-// coalesced gather per record) and read back as wave-uniform broadcasts (conflict-free), software-prefetched one
-// entry ahead.  A conservative wave-level test `power >= -ln(255 opacity) - margin` rejects a Gaussian for a whole
-// quadrant before the exp; survivors take the exact published test, so results are unchanged.
+// wave-uniform ballot + branch.  Batches of packed 48-B splat records (256 forward, 128 backward) are staged through LDS
+// (one coalesced gather per record) and read back as wave-uniform broadcasts (conflict-free) through a VGPR base with
+// immediate offsets, four entries per trip, prefetched two entries ahead.  Power is evaluated in the exp2 domain from the
+// pre-scaled conic of the record (5 VALU, bare v_exp_f32).  A conservative wave-level test `power >= log2(1/(255 opacity)) -
+// margin` rejects a Gaussian for a whole quadrant before the exp; survivors take the exact published test, so results are
+// unchanged.  Both kernels are bound by VALU issue (profiles/README.md): everything here is about instructions per hit.
 //
-// Backward: per-pixel back-to-front replay as published (T recovered by division), but NO global atomics:
-// each wave reduces its 64 pixels' contributions with a DPP scan (6 VALU/value), lane 63 adds the wave total
-// into a per-entry LDS accumulator, and the block writes one 48-B gradient record per (tile, instance) with
-// plain coalesced stores.  The per-Gaussian sum over instances happens in k_preprocess_bwd (deterministic).
+// Backward: per-pixel back-to-front replay as published (T recovered by division), but NO global atomics: each wave
+// reduces its 64 pixels' contributions by recursive halving (v_permlane32/16_swap + DPP, 24 VALU for nine sums) into a
+// private LDS slab, the block adds the four slabs in a fixed order and writes one 48-B gradient record per
+// (tile, instance) at the instance's emission slot.  The per-Gaussian sum over instances happens in k_preprocess_bwd
+// (deterministic).
 // Record = (sum g dx, sum g dy, sum g dx^2, sum g dx dy) (sum g dy^2, dL/dopacity_eff, d_r, d_g) (d_b, d_invdepth, -, -)
 // with g = dL/dpower and d = mean - pixel: raw moments; k_preprocess_bwd turns their per-Gaussian totals into
 // dL/dmean2D and dL/dconic.
