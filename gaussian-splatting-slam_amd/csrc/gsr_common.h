@@ -70,7 +70,9 @@ static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 #define GSR_SCAN_CHUNK (256 * GSR_SCAN_ITEMS)    // per block
 #define GSR_RADIX_BITS 8
 #define GSR_RADIX_SIZE 256
-#define GSR_RADIX_SUBTILES 16
+#define GSR_RADIX_SUBTILES 16                    // sub-tiles of 256 keys per workgroup (chunk = 4096 keys) for large arrays
+#define GSR_RADIX_SUBTILES_SMALL 8               // chunk = 2048 keys below GSR_RADIX_SMALL_N keys: twice the workgroups, so a
+#define GSR_RADIX_SMALL_N (2u << 20)             // 1 M-key depth sort still puts two workgroups on every CU
 #define GSR_RADIX_CHUNK (256 * GSR_RADIX_SUBTILES)
 
 static inline size_t gsr_scan_tmp_elems(size_t n) {
@@ -83,7 +85,11 @@ static inline size_t gsr_scan_tmp_elems(size_t n) {
   }
   return tot + 64;
 }
-static inline size_t gsr_radix_blocks(size_t n) { return (n + GSR_RADIX_CHUNK - 1) / GSR_RADIX_CHUNK; }
+static inline int gsr_radix_subtiles(size_t n) { return n < GSR_RADIX_SMALL_N ? GSR_RADIX_SUBTILES_SMALL : GSR_RADIX_SUBTILES; }
+static inline size_t gsr_radix_blocks(size_t n) {
+  const size_t chunk = (size_t)256 * gsr_radix_subtiles(n);
+  return (n + chunk - 1) / chunk;
+}
 static inline size_t gsr_radix_tmp_elems(size_t n) {
   size_t tab = GSR_RADIX_SIZE * (gsr_radix_blocks(n) + 1);
   return gsr_align(tab * 4) / 4 + gsr_scan_tmp_elems(tab);

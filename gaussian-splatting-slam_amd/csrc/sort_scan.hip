@@ -141,13 +141,13 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 //          over chunks + digit totals) -> k_radix_scatter (re-read the chunk, stable rank by wave ballots, scatter).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t* __restrict__ table,
-                                                    size_t n, int shift, uint32_t mask, uint32_t nblk) {
+                                                    size_t n, int shift, uint32_t mask, uint32_t nblk, int subtiles) {
   __shared__ uint32_t hist[GSR_RADIX_SIZE];
   hist[threadIdx.x] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * GSR_RADIX_CHUNK;
+  const size_t base = (size_t)blockIdx.x * 256 * subtiles;
 #pragma unroll 4
-  for (int s = 0; s < GSR_RADIX_SUBTILES; s++) {
+  for (int s = 0; s < subtiles; s++) {
     size_t k = base + (size_t)s * 256 + threadIdx.x;
     if (k < n) atomicAdd(&hist[(keys[k] >> shift) & mask], 1u);
   }
@@ -193,11 +193,9 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ ta
 //   phase 3  LDS is streamed out so that each digit's run lands in consecutive global addresses (64-B+ runs instead of the
 //            4-B scattered stores of a direct scatter).
 // Stable: equal digits keep (wave, sub-tile, lane) = original order.
-#define GSR_RADIX_WAVE_KEYS (GSR_RADIX_CHUNK / 4)
-#define GSR_RADIX_WAVE_TILES (GSR_RADIX_WAVE_KEYS / 64)
 // DUAL: a second 32-bit payload rides along (the tile sort carries the Gaussian id next to the emission slot, so no
 // gather by slot is needed afterwards).
-template <bool DUAL>
+template <bool DUAL, int SUBTILES>   // chunk = 256 * SUBTILES keys; wave w owns keys [64 SUBTILES w, 64 SUBTILES (w+1))
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                        const uint32_t* __restrict__ vals_in,
                                                        const uint32_t* __restrict__ vals2_in,
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
   __shared__ uint32_t wave_run[4][GSR_RADIX_SIZE];  // phase 1: keys of (wave, digit) seen so far; phase 2: the wave's base
   __shared__ uint32_t lstart[GSR_RADIX_SIZE];       // first local (sorted) position of each digit
   __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
-  __shared__ uint32_t lbuf[GSR_RADIX_CHUNK];        // ONE staging buffer, reused for keys, values (and the second payload):
+  __shared__ uint32_t lbuf[(256 * SUBTILES)];        // ONE staging buffer, reused for keys, values (and the second payload):
                                                     // 21 KB of LDS per workgroup instead of 36 / 52 -> 7 workgroups per CU
   __shared__ uint32_t lds4[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -221,15 +219,15 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
 #pragma unroll
   for (int i = 0; i < 4; i++) wave_run[i][tid] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * GSR_RADIX_CHUNK;
-  const uint32_t count = (uint32_t)min((size_t)GSR_RADIX_CHUNK, n - base);
+  const size_t base = (size_t)blockIdx.x * (256 * SUBTILES);
+  const uint32_t count = (uint32_t)min((size_t)(256 * SUBTILES), n - base);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const uint32_t wbase = (uint32_t)w * GSR_RADIX_WAVE_KEYS;
+  const uint32_t wbase = (uint32_t)w * (64 * SUBTILES);
   uint32_t* my_run = wave_run[w];
-  uint32_t key[GSR_RADIX_WAVE_TILES], val[GSR_RADIX_WAVE_TILES], rk[GSR_RADIX_WAVE_TILES];   // rk = digit << 16 | rank in (wave, digit)
-  uint32_t val2[DUAL ? GSR_RADIX_WAVE_TILES : 1];
+  uint32_t key[SUBTILES], val[SUBTILES], rk[SUBTILES];   // rk = digit << 16 | rank in (wave, digit)
+  uint32_t val2[DUAL ? SUBTILES : 1];
 #pragma unroll
-  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++) {
+  for (int s = 0; s < SUBTILES; s++) {
     const uint32_t li = wbase + (uint32_t)s * 64 + lane;
     const bool active = li < count;
     key[s] = active ? keys_in[base + li] : 0u;
@@ -237,7 +235,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     if (DUAL) val2[s] = active ? vals2_in[base + li] : 0u;
   }
 #pragma unroll
-  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++) {
+  for (int s = 0; s < SUBTILES; s++) {
     const uint32_t li = wbase + (uint32_t)s * 64 + lane;
     const bool active = li < count;
     const uint32_t d = active ? ((key[s] >> shift) & mask) : 0u;
@@ -270,18 +268,18 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
   __syncthreads();
   // local sorted position of each of this thread's keys
 #pragma unroll
-  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++) {
+  for (int s = 0; s < SUBTILES; s++) {
     const uint32_t d = rk[s] >> 16;
     rk[s] = lstart[d] + my_run[d] + (rk[s] & 0xFFFFu);
   }
   // round 1: keys through LDS; each thread also learns the global position of the sorted positions it streams out
-  uint32_t gpos[GSR_RADIX_SUBTILES];
+  uint32_t gpos[SUBTILES];
 #pragma unroll
-  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++)
+  for (int s = 0; s < SUBTILES; s++)
     if (wbase + (uint32_t)s * 64 + lane < count) lbuf[rk[s]] = key[s];
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < GSR_RADIX_SUBTILES; k++) {
+  for (int k = 0; k < SUBTILES; k++) {
     const uint32_t i = (uint32_t)k * 256 + tid;
     gpos[k] = 0;
     if (i < count) {
@@ -294,22 +292,22 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
   __syncthreads();
   // round 2: values
 #pragma unroll
-  for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++)
+  for (int s = 0; s < SUBTILES; s++)
     if (wbase + (uint32_t)s * 64 + lane < count) lbuf[rk[s]] = val[s];
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < GSR_RADIX_SUBTILES; k++) {
+  for (int k = 0; k < SUBTILES; k++) {
     const uint32_t i = (uint32_t)k * 256 + tid;
     if (i < count) vals_out[gpos[k]] = lbuf[i];
   }
   if (DUAL) {   // round 3: the second payload
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < GSR_RADIX_WAVE_TILES; s++)
+    for (int s = 0; s < SUBTILES; s++)
       if (wbase + (uint32_t)s * 64 + lane < count) lbuf[rk[s]] = val2[s];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < GSR_RADIX_SUBTILES; k++) {
+    for (int k = 0; k < SUBTILES; k++) {
       const uint32_t i = (uint32_t)k * 256 + tid;
       if (i < count) vals2_out[gpos[k]] = lbuf[i];
     }
@@ -320,6 +318,7 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
                          int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0, uint32_t* w1) {
   if (n == 0 || bits <= 0) return 0;
   const uint32_t nblk = (uint32_t)gsr_radix_blocks(n);
+  const int subtiles = gsr_radix_subtiles(n);
   uint32_t* table = tmp;
   uint32_t* totals = tmp + (size_t)GSR_RADIX_SIZE * nblk;     // sized by gsr_radix_tmp_elems: 256 * (nblk + 1)
   const bool dual = w0 != nullptr && w1 != nullptr;
@@ -333,16 +332,20 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
     uint32_t* vo = cur ? v0 : v1;
     const uint32_t* vin = (shift == 0 && vals_iota) ? nullptr : vi;
     GSR_LAUNCH("radix_hist", k_radix_hist, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, table, n, shift, mask,
-               nblk);
+               nblk, subtiles);
     GSR_LAUNCH("radix_rowscan", k_radix_rowscan, dim3(GSR_RADIX_SIZE), dim3(256), 0, st, table, totals, nblk);
-    if (dual)
-      GSR_LAUNCH("radix_scatter", k_radix_scatter<true>, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,
-                 (const uint32_t*)(cur ? w1 : w0), ko, vo, cur ? w0 : w1, (const uint32_t*)table,
-                 (const uint32_t*)totals, n, shift, mask, nblk);
-    else
-      GSR_LAUNCH("radix_scatter", k_radix_scatter<false>, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,
-                 (const uint32_t*)nullptr, ko, vo, (uint32_t*)nullptr, (const uint32_t*)table, (const uint32_t*)totals, n,
-                 shift, mask, nblk);
+#define GSR_SCATTER(D, S)                                                                                              \
+  GSR_LAUNCH("radix_scatter", (k_radix_scatter<D, S>), dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,         \
+             (const uint32_t*)(D ? (cur ? w1 : w0) : nullptr), ko, vo, (uint32_t*)(D ? (cur ? w0 : w1) : nullptr),      \
+             (const uint32_t*)table, (const uint32_t*)totals, n, shift, mask, nblk)
+    if (dual) {
+      if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_SCATTER(true, GSR_RADIX_SUBTILES_SMALL);
+      else GSR_SCATTER(true, GSR_RADIX_SUBTILES);
+    } else {
+      if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_SCATTER(false, GSR_RADIX_SUBTILES_SMALL);
+      else GSR_SCATTER(false, GSR_RADIX_SUBTILES);
+    }
+#undef GSR_SCATTER
     cur ^= 1;
   }
   return cur;

@@ -87,3 +87,42 @@ def test_render_raw_parameter_path_matches_getter_path():
     # 2e-4 relative, with an absolute floor of 1e-5 of the largest entry
     for x, y in zip(outs[0][1] + [outs[0][2]], outs[1][1] + [outs[1][2]]):
         torch.testing.assert_close(x, y, rtol=2e-4, atol=1e-5 * float(y.abs().max()))
+
+
+def test_rasterizer_raw_activations_flag_with_aa_depth_and_scale_modifier():
+    """`GaussianRasterizer.forward(..., raw_activations=True)` on the raw parameters against the same rasterizer fed with
+    torch.exp / F.normalize / torch.sigmoid of them (autograd through the PyTorch ops): anti-aliasing on (the opacity
+    enters the AA factor), scale_modifier != 1, gradient on colour and inverse depth, the dc / rest call form.  Forward
+    differences come only from the last-bit rounding of the activations; gradients agree to 2e-4 relative."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from helpers import settings_for, upstream_grads
+    from scene_utils.cameras import look_at_camera
+    from scene_utils.synthetic import make_gaussians
+
+    raw = make_gaussians(1800, 3, seed=21).to("cuda")
+    cam = look_at_camera((0.5, -4.0, 0.8), (0, 0, 0), (0, 0, 1), 1.0, 112, 80).to("cuda")
+    bg = torch.tensor([0.2, 0.1, 0.0], device="cuda")
+    rs = settings_for(cam, 3, bg, scale_modifier=1.3, antialiasing=True, cls=GaussianRasterizationSettings, device="cuda")
+    gc, gd = (t.cuda() for t in upstream_grads(80, 112))
+    res = []
+    for use_raw in (True, False):
+        xyz = raw.xyz.clone().requires_grad_(True)
+        s, q, o = (t.clone().requires_grad_(True) for t in (raw.scaling, raw.rotation, raw.opacity))
+        dc = raw.features_dc.clone().requires_grad_(True)
+        rest = raw.features_rest.clone().requires_grad_(True)
+        m2d = torch.zeros_like(xyz, requires_grad=True)
+        if use_raw:
+            kw = dict(opacities=o, scales=s, rotations=q, raw_activations=True)
+        else:
+            kw = dict(opacities=torch.sigmoid(o), scales=torch.exp(s), rotations=torch.nn.functional.normalize(q))
+        color, radii, invd = GaussianRasterizer(rs)(means3D=xyz, means2D=m2d, dc=dc, shs=rest, **kw)
+        ((color * gc).sum() + (invd * gd).sum()).backward()
+        res.append((color.detach(), invd.detach(), radii, [t.grad.clone() for t in (xyz, s, q, o, dc, rest, m2d)]))
+    (c0, d0, r0, g0), (c1, d1, r1, g1) = res
+    assert int((r0 > 0).sum()) > 300
+    assert int((r0 != r1).sum()) <= 2
+    diff = (c0 - c1).abs().amax(dim=0)
+    assert int((diff >= 2e-5).sum()) <= 3 and float(diff.max()) < 5e-3      # at most a few alpha-threshold flips
+    assert float((d0 - d1).abs().max()) < 5e-3
+    for a, b in zip(g0, g1):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-20)) < 2e-4
