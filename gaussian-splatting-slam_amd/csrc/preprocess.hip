@@ -141,21 +141,45 @@ __device__ __forceinline__ float sh_coef(const float* dc, const float* shs, int 
 // hits 32 distinct banks across the wave), and the gradient rows go back to HBM the same way.
 // (row, column) of flat element e = 4 i is carried incrementally from trip to trip (i advances by 256, e by 1024): one
 // runtime division per thread instead of one per 16-B piece.
-__device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int nflt, int S, int Sp, float* lds) {
+// `need` (optional; an LDS array, one int per row, > 0 = wanted): rows nobody will read - culled Gaussians, a third of the
+// bench scene and most of a room-scale capture - are not fetched; their LDS rows stay undefined.  All the loads of a thread
+// are issued before the first LDS store (a predicated load followed by its own store would serialise the fetches).
+#define GSR_STAGE_MAX_TRIPS 16     // 256 rows x S floats / 4 / 256 threads = S / 4 <= 16 (can_stage_sh caps S at 63)
+__device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int nflt, int S, int Sp, float* lds,
+                                              const int32_t* need = nullptr) {
   const int n4 = nflt >> 2;
   const int dr = 1024 / S, dc = 1024 - dr * S;                 // (row, column) advance per trip
-  int r = (threadIdx.x * 4) / S, c = threadIdx.x * 4 - r * S;
-  for (int i = threadIdx.x; i < n4; i += 256) {
-    const float4 v = gsr_ld_stream4(reinterpret_cast<const float4*>(src) + i);   // SH rows pass through once per kernel
-    const float vv[4] = {v.x, v.y, v.z, v.w};
-    int rr = r, cc = c;
+  const int r0 = (threadIdx.x * 4) / S, c0 = threadIdx.x * 4 - r0 * S;
+  float4 v[GSR_STAGE_MAX_TRIPS];
+  bool want[GSR_STAGE_MAX_TRIPS];
+  {
+    int r = r0, c = c0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      lds[rr * Sp + cc] = vv[k];
-      if (++cc == S) { cc = 0; rr++; }
+    for (int it = 0; it < GSR_STAGE_MAX_TRIPS; it++) {
+      const int i = threadIdx.x + 256 * it;
+      want[it] = i < n4;
+      if (want[it] && need) want[it] = need[r] > 0 || (c + 3 >= S && (r + 1) * S < nflt && need[r + 1] > 0);   // may straddle 2 rows
+      if (want[it]) v[it] = gsr_ld_stream4(reinterpret_cast<const float4*>(src) + i);   // SH rows pass through once per kernel
+      r += dr; c += dc;
+      if (c >= S) { c -= S; r++; }
     }
-    r += dr; c += dc;
-    if (c >= S) { c -= S; r++; }
+  }
+  {
+    int r = r0, c = c0;
+#pragma unroll
+    for (int it = 0; it < GSR_STAGE_MAX_TRIPS; it++) {
+      if (want[it]) {
+        const float vv[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        int rr = r, cc = c;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          lds[rr * Sp + cc] = vv[k];
+          if (++cc == S) { cc = 0; rr++; }
+        }
+      }
+      r += dr; c += dc;
+      if (c >= S) { c -= S; r++; }
+    }
   }
   for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {
     const int r2 = e / S, c2 = e - r2 * S;
@@ -230,155 +254,174 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     float4* __restrict__ bin_rec,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+  __shared__ int32_t need_sh[256];     // STAGE: which SH rows of this workgroup will be evaluated
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int S = 3 * sh_stride, Sp = S | 1;
+  const bool in_range = idx < P;
+  const float* my_row = sh_lds + threadIdx.x * Sp;
+
+  // ---- phase 1: geometry (no SH needed); what phase 2 needs stays in registers ----
+  int32_t out_radius = 0;                       // defaults for a culled Gaussian
+  uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu;
+  bool on_screen = false;                       // passed the near plane, det != 0, non-empty 3-sigma rectangle
+  float px = 0.f, py = 0.f, sA = 0.f, sB = 0.f, sC = 0.f, op = 0.f, spmin = 0.f, depth = 1.f;
+  int cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;
+  float p[3] = {0.f, 0.f, 0.f};
+  if (in_range) {
+    PreView v;
+    load_view(viewmatrix, projmatrix, campos, v);
+    p[0] = means3D[3 * (size_t)idx];
+    p[1] = means3D[3 * (size_t)idx + 1];
+    p[2] = means3D[3 * (size_t)idx + 2];
+    float t[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = v.V[i] * p[0] + v.V[4 + i] * p[1] + v.V[8 + i] * p[2] + v.V[12 + i];
+    depth = t[2];
+
+    if (t[2] > 0.2f) {  // A.1 near-plane cull only
+      float hom[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) hom[i] = v.PV[i] * p[0] + v.PV[4 + i] * p[1] + v.PV[8 + i] * p[2] + v.PV[12 + i];
+      const float pw = 1.0f / (hom[3] + 0.0000001f);
+      const float ndcx = hom[0] * pw, ndcy = hom[1] * pw;
+
+      float cov6[6];
+      if (cov3D_precomp) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov6[i] = cov3D_precomp[6 * (size_t)idx + i];
+      } else {
+        float s3[3], q4[4], qden;
+        load_scale_rot(scales, rotations, (size_t)idx, raw_act, s3, q4, qden);
+        cov3d_from_sr(s3, q4, scale_modifier, cov6, nullptr);
+      }
+      const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
+      Ewa e;
+      ewa_project(t, v, cov6, fx, fy, tanfovx, tanfovy, e);
+
+      // A.3 dilation / AA
+      const float det0 = e.a0 * e.c0 - e.b * e.b;
+      const float a = e.a0 + 0.3f, c = e.c0 + 0.3f, b = e.b;
+      const float det = a * c - b * b;
+      float h = 1.0f;
+      if (antialiasing) h = sqrtf(fmaxf(0.000025f, det0 / det));
+      if (det != 0.0f) {
+        const float det_inv = 1.0f / det;
+        const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
+        // A.4 extent
+        const float mid = 0.5f * (a + c);
+        const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lam = fmaxf(mid + root, mid - root);
+        const float radius = ceilf(3.0f * sqrtf(lam));
+        px = ((ndcx + 1.0f) * W - 1.0f) * 0.5f;
+        py = ((ndcy + 1.0f) * H - 1.0f) * 0.5f;
+        const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+        // C-style truncation then clamp; guard the float->int conversion against huge values
+        const float lim = 1.0e9f;
+        const int x0 = min(gx, max(0, (int)fminf(lim, fmaxf(-lim, (px - radius) / GSR_TILE))));
+        const int y0 = min(gy, max(0, (int)fminf(lim, fmaxf(-lim, (py - radius) / GSR_TILE))));
+        const int x1 = min(gx, max(0, (int)fminf(lim, fmaxf(-lim, (px + radius + (GSR_TILE - 1)) / GSR_TILE))));
+        const int y1 = min(gy, max(0, (int)fminf(lim, fmaxf(-lim, (py + radius + (GSR_TILE - 1)) / GSR_TILE))));
+        const int area = (x1 - x0) * (y1 - y0);
+        if (area > 0) {
+          on_screen = true;
+          op = load_opacity(opacities, (size_t)idx, raw_act) * h;
+          // conservative cut-off for the render kernels: alpha = op*exp(power) >= 1/255  <=>  power >= -ln(255 op);
+          // the margin (>> fp32 error of power / exp) keeps the test a pure accelerator (exact test follows it)
+          const float pmin = (op > 0.f) ? (-logf(255.0f * op) - 0.01f) : 1.0f;
+          // Exact tile culling: a pixel can only blend this Gaussian if d^T conic d <= q = -2 pmin.  That ellipse lies in
+          // the axis-aligned box |dx| <= sqrt(q * cov_xx), |dy| <= sqrt(q * cov_yy) (cov = dilated 2-D covariance =
+          // conic^-1), so tiles of the published 3-sigma rectangle outside the box cannot contribute to the image or to
+          // any gradient and are not emitted.  Outputs are unchanged; only the internal instance lists get shorter
+          // (-26 % at C3).  `rect` keeps the (shrunk) box; emit applies the per-row test below inside it.
+          cx0 = x0; cy0 = y0; cx1 = x1; cy1 = y1;
+          {
+            const float q = -2.0f * pmin;
+            if (q <= 0.f) {
+              cx1 = cx0;  // opacity below 1/255: never blended anywhere
+            } else {
+              const float hx = sqrtf(q * a) * 1.0001f + 0.01f, hy = sqrtf(q * c) * 1.0001f + 0.01f;
+              // tile t holds pixel centres 16t .. 16t+15
+              const int tx_lo = (int)ceilf(fmaxf(-lim, (px - hx - (GSR_TILE - 1)) / GSR_TILE));
+              const int tx_hi = (int)floorf(fminf(lim, (px + hx) / GSR_TILE));
+              const int ty_lo = (int)ceilf(fmaxf(-lim, (py - hy - (GSR_TILE - 1)) / GSR_TILE));
+              const int ty_hi = (int)floorf(fminf(lim, (py + hy) / GSR_TILE));
+              cx0 = max(cx0, tx_lo); cx1 = min(cx1, tx_hi + 1);
+              cy0 = max(cy0, ty_lo); cy1 = min(cy1, ty_hi + 1);
+            }
+          }
+          // second stage inside the box: exact per-row column intervals of the ellipse (another -12 % at C3); emit repeats
+          // the same computation bit-identically (same stored inputs, same compiled body)
+          sA = (-0.5f * GSR_LOG2E) * cA; sB = -GSR_LOG2E * cB; sC = (-0.5f * GSR_LOG2E) * cC;
+          spmin = GSR_LOG2E * pmin;
+          int kept = 0;
+          for (int ty = cy0; ty < cy1; ty++) {
+            const uint32_t iv = gsr_row_interval(px, py, sA, sB, sC, spmin, ty, cx0, cx1);
+            kept += (int)(iv >> 16) - (int)(iv & 0xFFFFu);
+          }
+          if (kept == 0) { cx0 = cx1 = cy0 = cy1 = 0; }
+          out_radius = (int32_t)radius;        // radii / visibility are the published ones (3-sigma rectangle non-empty)
+          out_tiles = (uint32_t)kept;
+          out_key = __float_as_uint(t[2]);
+        }
+      }
+    } else if (prefiltered) {
+      meta[1] = 1u;  // prefiltered point failed the near-plane test (hard error upstream)
+    }
+  }
+
+  // ---- phase 2: colour.  Only Gaussians that reach at least one tile need their SH row: the workgroup fetches just those
+  // rows (a third of the bench scene is culled, most of a room-scale capture is), still as flat coalesced 16-B pieces ----
+  const bool want_sh = on_screen && out_tiles != 0 && !colors_precomp && !defer_color;
   if (STAGE) {
+    need_sh[threadIdx.x] = want_sh ? 1 : 0;
+    __syncthreads();
     const size_t row0 = (size_t)blockIdx.x * 256;
     const int rows = (int)min((size_t)256, (size_t)P - row0);
-    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds);
+    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds, need_sh);
     __syncthreads();
   }
-  if (idx >= P) return;
-  const float* my_row = sh_lds + threadIdx.x * Sp;
-  PreView v;
-  load_view(viewmatrix, projmatrix, campos, v);
-
-  // defaults for a culled Gaussian
-  int32_t out_radius = 0;
-  uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu;
-
-  const float p[3] = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
-  float t[3];
+  if (on_screen) {
+    // rgb stays 0 for deferred colour (k_shade fills it, and `clamped`, right before compositing) and for a Gaussian whose
+    // alpha >= 1/255 ellipse reaches no tile (never composited, and the backward skips it)
+    float rgb[3] = {0.f, 0.f, 0.f};
+    uint8_t cl = 0;
+    if (colors_precomp) {
+      rgb[0] = colors_precomp[3 * (size_t)idx];
+      rgb[1] = colors_precomp[3 * (size_t)idx + 1];
+      rgb[2] = colors_precomp[3 * (size_t)idx + 2];
+    } else if (want_sh) {
+      float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= inv; dy *= inv; dz *= inv;
+      float bs[16];
+      sh_basis_eval(deg, dx, dy, dz, bs);
+      const int K = (deg + 1) * (deg + 1);
+      for (int k = 0; k < K; k++) {
 #pragma unroll
-  for (int i = 0; i < 3; i++) t[i] = v.V[i] * p[0] + v.V[4 + i] * p[1] + v.V[8 + i] * p[2] + v.V[12 + i];
-
-  if (t[2] > 0.2f) {  // A.1 near-plane cull only
-    float hom[4];
+        for (int ch = 0; ch < 3; ch++)
+          rgb[ch] += bs[k] * (STAGE ? sh_coef_lds(dc, my_row, idx, k, ch) : sh_coef(dc, shs, sh_stride, idx, k, ch));
+      }
 #pragma unroll
-    for (int i = 0; i < 4; i++) hom[i] = v.PV[i] * p[0] + v.PV[4 + i] * p[1] + v.PV[8 + i] * p[2] + v.PV[12 + i];
-    const float pw = 1.0f / (hom[3] + 0.0000001f);
-    const float ndcx = hom[0] * pw, ndcy = hom[1] * pw;
-
-    float cov6[6];
-    if (cov3D_precomp) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) cov6[i] = cov3D_precomp[6 * (size_t)idx + i];
-    } else {
-      float s3[3], q4[4], qden;
-      load_scale_rot(scales, rotations, (size_t)idx, raw_act, s3, q4, qden);
-      cov3d_from_sr(s3, q4, scale_modifier, cov6, nullptr);
-    }
-    const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
-    Ewa e;
-    ewa_project(t, v, cov6, fx, fy, tanfovx, tanfovy, e);
-
-    // A.3 dilation / AA
-    const float det0 = e.a0 * e.c0 - e.b * e.b;
-    const float a = e.a0 + 0.3f, c = e.c0 + 0.3f, b = e.b;
-    const float det = a * c - b * b;
-    float h = 1.0f;
-    if (antialiasing) h = sqrtf(fmaxf(0.000025f, det0 / det));
-    if (det != 0.0f) {
-      const float det_inv = 1.0f / det;
-      const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
-      // A.4 extent
-      const float mid = 0.5f * (a + c);
-      const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
-      const float lam = fmaxf(mid + root, mid - root);
-      const float radius = ceilf(3.0f * sqrtf(lam));
-      const float px = ((ndcx + 1.0f) * W - 1.0f) * 0.5f;
-      const float py = ((ndcy + 1.0f) * H - 1.0f) * 0.5f;
-      const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
-      // C-style truncation then clamp; guard the float->int conversion against huge values
-      const float lim = 1.0e9f;
-      const int x0 = min(gx, max(0, (int)fminf(lim, fmaxf(-lim, (px - radius) / GSR_TILE))));
-      const int y0 = min(gy, max(0, (int)fminf(lim, fmaxf(-lim, (py - radius) / GSR_TILE))));
-      const int x1 = min(gx, max(0, (int)fminf(lim, fmaxf(-lim, (px + radius + (GSR_TILE - 1)) / GSR_TILE))));
-      const int y1 = min(gy, max(0, (int)fminf(lim, fmaxf(-lim, (py + radius + (GSR_TILE - 1)) / GSR_TILE))));
-      const int area = (x1 - x0) * (y1 - y0);
-      if (area > 0) {
-        float rgb[3];
-        uint8_t cl = 0;
-        if (colors_precomp) {
-          rgb[0] = colors_precomp[3 * (size_t)idx];
-          rgb[1] = colors_precomp[3 * (size_t)idx + 1];
-          rgb[2] = colors_precomp[3 * (size_t)idx + 2];
-        } else if (defer_color) {
-          rgb[0] = rgb[1] = rgb[2] = 0.f;   // k_shade fills the colour (and `clamped`) right before compositing
-        } else {
-          float dx = p[0] - v.cam[0], dy = p[1] - v.cam[1], dz = p[2] - v.cam[2];
-          const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-          dx *= inv; dy *= inv; dz *= inv;
-          float bs[16];
-          sh_basis_eval(deg, dx, dy, dz, bs);
-          const int K = (deg + 1) * (deg + 1);
-          rgb[0] = rgb[1] = rgb[2] = 0.f;
-          for (int k = 0; k < K; k++) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-              rgb[ch] += bs[k] * (STAGE ? sh_coef_lds(dc, my_row, idx, k, ch) : sh_coef(dc, shs, sh_stride, idx, k, ch));
-          }
-#pragma unroll
-          for (int ch = 0; ch < 3; ch++) {
-            rgb[ch] += 0.5f;
-            if (rgb[ch] < 0.f) { cl |= (1u << ch); rgb[ch] = 0.f; }
-          }
-        }
-        const float op = load_opacity(opacities, (size_t)idx, raw_act) * h;
-        // conservative cut-off for the render kernels: alpha = op*exp(power) >= 1/255  <=>  power >= -ln(255 op);
-        // the margin (>> fp32 error of power / exp) keeps the test a pure accelerator (exact test follows it)
-        const float pmin = (op > 0.f) ? (-logf(255.0f * op) - 0.01f) : 1.0f;
-        // Exact tile culling: a pixel can only blend this Gaussian if d^T conic d <= q = -2 pmin.  That ellipse lies in
-        // the axis-aligned box |dx| <= sqrt(q * cov_xx), |dy| <= sqrt(q * cov_yy) (cov = dilated 2-D covariance = conic^-1),
-        // so tiles of the published 3-sigma rectangle outside the box cannot contribute to the image or to any gradient
-        // and are not emitted.  Outputs are unchanged; only the internal instance lists get shorter (-26 % at C3).
-        // `rect` keeps the (shrunk) box; emit applies the per-tile test below inside it.
-        int cx0 = x0, cy0 = y0, cx1 = x1, cy1 = y1;
-        {
-          const float q = -2.0f * pmin;
-          if (q <= 0.f) {
-            cx1 = cx0;  // opacity below 1/255: never blended anywhere
-          } else {
-            const float hx = sqrtf(q * a) * 1.0001f + 0.01f, hy = sqrtf(q * c) * 1.0001f + 0.01f;
-            // tile t holds pixel centres 16t .. 16t+15
-            const int tx_lo = (int)ceilf(fmaxf(-lim, (px - hx - (GSR_TILE - 1)) / GSR_TILE));
-            const int tx_hi = (int)floorf(fminf(lim, (px + hx) / GSR_TILE));
-            const int ty_lo = (int)ceilf(fmaxf(-lim, (py - hy - (GSR_TILE - 1)) / GSR_TILE));
-            const int ty_hi = (int)floorf(fminf(lim, (py + hy) / GSR_TILE));
-            cx0 = max(cx0, tx_lo); cx1 = min(cx1, tx_hi + 1);
-            cy0 = max(cy0, ty_lo); cy1 = min(cy1, ty_hi + 1);
-          }
-        }
-        // second stage inside the box: exact per-row column intervals of the ellipse (another -12 % at C3); emit repeats the
-        // same computation bit-identically (same stored inputs, same compiled body)
-        const float sA = (-0.5f * GSR_LOG2E) * cA, sB = -GSR_LOG2E * cB, sC = (-0.5f * GSR_LOG2E) * cC;
-        const float spmin = GSR_LOG2E * pmin;
-        int kept = 0;
-        for (int ty = cy0; ty < cy1; ty++) {
-          const uint32_t iv = gsr_row_interval(px, py, sA, sB, sC, spmin, ty, cx0, cx1);
-          kept += (int)(iv >> 16) - (int)(iv & 0xFFFFu);
-        }
-        if (kept == 0) { cx0 = cx1 = cy0 = cy1 = 0; }
-        rec[3 * (size_t)idx + 0] = make_float4(px, py, sA, sB);
-        rec[3 * (size_t)idx + 1] = make_float4(sC, op, spmin, rgb[0]);
-        rec[3 * (size_t)idx + 2] = make_float4(rgb[1], rgb[2], 1.0f / t[2], t[2]);
-        rect[idx] = make_ushort4((unsigned short)cx0, (unsigned short)cy0, (unsigned short)cx1, (unsigned short)cy1);
-        // the emit pass walks the Gaussians in DEPTH order: one 32-B gather per Gaussian instead of three (record, rect, count)
-        bin_rec[2 * (size_t)idx + 0] = make_float4(px, py, sA, sB);
-        bin_rec[2 * (size_t)idx + 1] = make_float4(sC, spmin, __uint_as_float((uint32_t)cx0 | ((uint32_t)cy0 << 16)),
-                                                   __uint_as_float((uint32_t)cx1 | ((uint32_t)cy1 << 16)));
-        clamped[idx] = cl;
-        out_radius = (int32_t)radius;        // radii / visibility are the published ones (3-sigma rectangle non-empty)
-        out_tiles = (uint32_t)kept;
-        out_key = __float_as_uint(t[2]);
+      for (int ch = 0; ch < 3; ch++) {
+        rgb[ch] += 0.5f;
+        if (rgb[ch] < 0.f) { cl |= (1u << ch); rgb[ch] = 0.f; }
       }
     }
-  } else if (prefiltered) {
-    meta[1] = 1u;  // prefiltered point failed the near-plane test (hard error upstream)
+    rec[3 * (size_t)idx + 0] = make_float4(px, py, sA, sB);
+    rec[3 * (size_t)idx + 1] = make_float4(sC, op, spmin, rgb[0]);
+    rec[3 * (size_t)idx + 2] = make_float4(rgb[1], rgb[2], 1.0f / depth, depth);
+    rect[idx] = make_ushort4((unsigned short)cx0, (unsigned short)cy0, (unsigned short)cx1, (unsigned short)cy1);
+    // the emit pass walks the Gaussians in DEPTH order: one 32-B gather per Gaussian instead of three (record, rect, count)
+    bin_rec[2 * (size_t)idx + 0] = make_float4(px, py, sA, sB);
+    bin_rec[2 * (size_t)idx + 1] = make_float4(sC, spmin, __uint_as_float((uint32_t)cx0 | ((uint32_t)cy0 << 16)),
+                                               __uint_as_float((uint32_t)cx1 | ((uint32_t)cy1 << 16)));
+    clamped[idx] = cl;
   }
-  radii[idx] = out_radius;
-  tiles_touched[idx] = out_tiles;
-  depth_key[idx] = out_key;   // `order` is not written: the depth sort takes value = index on its first pass
+  if (in_range) {
+    radii[idx] = out_radius;
+    tiles_touched[idx] = out_tiles;
+    depth_key[idx] = out_key;   // `order` is not written: the depth sort takes value = index on its first pass
+  }
 }
 
 // num_rendered = sum of tiles_touched does not depend on the depth order: summed right after the projection (integer
@@ -426,12 +469,15 @@ __global__ __launch_bounds__(256) void k_shade(int P, int deg, int sh_stride, co
                                                const uint32_t* __restrict__ tiles_touched, float4* __restrict__ rec,
                                                uint8_t* __restrict__ clamped) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+  __shared__ int32_t need_sh[256];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int S = 3 * sh_stride, Sp = S | 1;
   if (STAGE) {
     const size_t row0 = (size_t)blockIdx.x * 256;
     const int rows = (int)min((size_t)256, (size_t)P - row0);
-    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds);
+    need_sh[threadIdx.x] = (int)threadIdx.x < rows ? (int32_t)min(tiles_touched[row0 + threadIdx.x], 1u) : 0;
+    __syncthreads();
+    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds, need_sh);
     __syncthreads();
   }
   if (idx >= P || tiles_touched[idx] == 0) return;
@@ -483,18 +529,23 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dcov3D) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+  __shared__ int32_t need_sh[256];
   const int S = 3 * sh_stride, Sp = S | 1;
   const size_t row0 = (size_t)blockIdx.x * 256;
   const int rows = (int)min((size_t)256, (size_t)P - row0);
   if (STAGE) {
-    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds);
+    need_sh[threadIdx.x] = (int)threadIdx.x < rows ? (int32_t)min(tiles_touched[row0 + threadIdx.x], 1u) : 0;
+    __syncthreads();
+    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds, need_sh);   // only the rows of Gaussians with instances are read below
     __syncthreads();
   }
   float* my_row = sh_lds + threadIdx.x * Sp;
   const bool active = blockIdx.x * 256 + threadIdx.x < P;
   const int idx = active ? blockIdx.x * 256 + threadIdx.x : P - 1;   // idle tail threads mirror the last Gaussian (no stores)
   const int K = (deg + 1) * (deg + 1);
-  const bool visible = radii[idx] > 0;
+  // A Gaussian that reached no tile (culled, or its alpha >= 1/255 ellipse misses every tile centre row) has no gradient
+  // records: all its gradients are exact zeros, written below without touching its inputs.
+  const bool visible = tiles_touched[idx] > 0;
 
   float g_mean[3] = {0.f, 0.f, 0.f};
   float g_m2d[2] = {0.f, 0.f};
