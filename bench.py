@@ -271,11 +271,13 @@ def main():
 
     for i in range(args.warmup):
         trainer.step(views_of_step(i))
+    trainer.finish()       # an SH update handed to "the next forward" belongs to the step that produced it: flush it here ...
     barrier()
     log("warmup done")
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.step(views_of_step(args.warmup + i))
+    trainer.finish()       # ... and here, so the timed region holds exactly K complete optimizer steps
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -327,6 +329,7 @@ def main():
         for i in range(nprof):
             trainer.step(view_at(i))
             Rs.append(dgr.last_call_stats["num_rendered"])   # measured R of each profiled view
+        trainer.finish()
         torch.cuda.synchronize()
         prof = _C.profile_read()
         lib.gsr_profile_enable(0)

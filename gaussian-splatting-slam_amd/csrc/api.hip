@@ -273,9 +273,9 @@ int gsr_forward_shade(const gsr_settings* s, const gsr_gaussians* g, void* geome
   return gsr_check(hipGetLastError(), "shade launch");
 }
 
-int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
-                       size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
-                       float* out_color, float* out_invdepth, int32_t for_backward, void* stream) {
+static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
+                               size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
+                               float* out_color, float* out_invdepth, bool shade_late, hipEvent_t sh_ready, void* stream) {
   int rc = validate(s, g);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -309,11 +309,35 @@ int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geom
     gsr_launch_finalize((uint32_t)R, ks, bin, BL, st);
     if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
   }
+  if (shade_late && g->P > 0) {
+    // the colours are the LAST thing the compositing needs: everything above ran without the SH coefficients, which may
+    // still be receiving their update on another stream
+    if (sh_ready && (rc = gsr_check(hipStreamWaitEvent(st, sh_ready, 0), "wait for the SH coefficients"))) return rc;
+    gsr_launch_shade(s, g, geom, GL, st);
+    if ((rc = debug_sync(s, st, "shade"))) return rc;
+  }
   gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                         (const float4*)(geom + GL.rec), out_color, out_invdepth, (float*)(img + IL.final_T),
                         (uint32_t*)(img + IL.n_contrib), st);
   if ((rc = debug_sync(s, st, "render forward"))) return rc;
   return gsr_check(hipGetLastError(), "forward launch");
+}
+
+int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
+                       size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
+                       float* out_color, float* out_invdepth, int32_t for_backward, void* stream) {
+  (void)for_backward;
+  return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, num_rendered, image_state, image_bytes,
+                             out_color, out_invdepth, false, nullptr, stream);
+}
+
+int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
+                             size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
+                             float* out_color, float* out_invdepth, int32_t for_backward, void* sh_ready_event,
+                             void* stream) {
+  (void)for_backward;
+  return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, num_rendered, image_state, image_bytes,
+                             out_color, out_invdepth, true, (hipEvent_t)sh_ready_event, stream);
 }
 
 int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,

@@ -129,19 +129,23 @@ class _RasterizeGaussians(torch.autograd.Function):
             ev, _sh_ready_event = _sh_ready_event, None
             try:
                 if ev is not None and colors_precomp is None:
+                    # split forward: geometry stages, emission + tile sort, THEN wait for the SH update, shade, composite
                     R = _C.check(lib.gsr_forward_prepare_geometry(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(),
                                                                   _C.ptr(radii), _stream()))
-                    torch.cuda.current_stream().wait_event(ev)     # SH coefficients of this step are final after this
-                    _C.check(lib.gsr_forward_shade(C.byref(s), C.byref(g), _C.ptr(geom), _stream()))
+                    binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
+                    evh = C.c_void_p(ev.cuda_event)
+                    _C.check(lib.gsr_forward_render_shade(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning),
+                                                          binning.numel(), R, _C.ptr(img), img.numel(), _C.ptr(color),
+                                                          _C.ptr(invdepth), 1 if needs_grad else 0, evh, _stream()))
                 else:
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
                     R = _C.check(lib.gsr_forward_prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(),
                                                          _C.ptr(radii), _stream()))
-                binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
-                _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning), binning.numel(),
-                                                R, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invdepth),
-                                                1 if needs_grad else 0, _stream()))
+                    binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
+                    _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning), binning.numel(),
+                                                    R, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invdepth),
+                                                    1 if needs_grad else 0, _stream()))
             except _C.GsrError:
                 if rs.debug:   # reference README.md:168-169: with --debug a failing rasterizer call dumps its inputs
                     _dump("snapshot_fw.dump", rs, means3D, dc, sh, colors_precomp, opacities, scales, rotations,

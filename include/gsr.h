@@ -129,7 +129,16 @@ int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geom
                        size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
                        void* stream);
 
-/* Backward of the call above.  dL_dinvdepth may be NULL (treated as zero). */
+/* gsr_forward_prepare_geometry's companion that evaluates the colours as LATE as possible: instance emission, tile sort and
+ * tile ranges run first (none of them reads `dc` / `shs`), then `stream` waits for `sh_ready_event` (a hipEvent_t recorded by
+ * the caller after the SH coefficients' update; NULL = no wait), then the SH -> RGB pass (what gsr_forward_shade does), then
+ * the compositing: the whole binning stage overlaps an SH exchange / update running on another stream.  Same results. */
+int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
+                             void* binning_state, size_t binning_bytes, int64_t num_rendered, void* image_state,
+                             size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
+                             void* sh_ready_event, void* stream);
+
+/* Backward of the calls above.  dL_dinvdepth may be NULL (treated as zero). */
 int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii,
                  const void* geometry_state, const void* binning_state, const void* image_state,
                  int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth,

@@ -121,6 +121,7 @@ def test_training_with_densification_schedule():
         out = tr.step(it % 3)
         sizes.append(model.get_xyz.shape[0])
         assert torch.isfinite(out["loss"])
+    tr.finish()
     assert len(set(sizes)) > 2
     assert model.xyz_gradient_accum.shape[0] == sizes[-1]
 
