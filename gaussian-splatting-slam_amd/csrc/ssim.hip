@@ -31,10 +31,37 @@ static SsimWindow make_window() {
   return w;
 }
 
+
+// XCD-aware tile order.  Consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so with the natural
+// (x, y, plane) order two x-adjacent tiles - which share a 10-pixel halo - never share an L2 and every halo is fetched from
+// the fabric again (PMC: k_ssim_bwd read 339 MB for 125 MB of input).  Workgroup b instead takes tile
+// (b % 8) * ceil(n / 8) + b / 8: each XCD walks ONE contiguous strip of the (plane, y, x) order and keeps its halos in L2.
+// The launch is 1-D with 8 * ceil(n / 8) workgroups; the few past the end return at once.
+#define SSIM_XCDS 8
+struct SsimTile { int tx, ty, plane; long long lin; bool valid; };
+__device__ __forceinline__ SsimTile ssim_tile(int gx, int gy, int planes) {
+  const long long n = (long long)gx * gy * planes;
+  const long long per = (n + SSIM_XCDS - 1) / SSIM_XCDS;
+  const long long lin = (long long)(blockIdx.x % SSIM_XCDS) * per + blockIdx.x / SSIM_XCDS;
+  SsimTile t;
+  t.lin = lin;
+  t.valid = lin < n;
+  const long long l = t.valid ? lin : 0;
+  t.plane = (int)(l / ((long long)gx * gy));
+  const int rem = (int)(l - (long long)t.plane * gx * gy);
+  t.ty = rem / gx;
+  t.tx = rem - t.ty * gx;
+  return t;
+}
+static inline unsigned ssim_grid(int gx, int gy, int planes) {
+  const long long n = (long long)gx * gy * planes;
+  return (unsigned)(((n + SSIM_XCDS - 1) / SSIM_XCDS) * SSIM_XCDS);
+}
+
 // `partials` != NULL: the kernel also reduces sum(ssim) and sum(|img1-img2|) over its tile into partials[2*block .. +1]
 // (fixed in-block order; the host adds the per-block pairs in index order -> deterministic), which is all the fused
 // L1 + D-SSIM training loss needs; `ssim_map` may then be NULL.
-__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float C2, SsimWindow win,
+__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int planes, float C1, float C2, SsimWindow win,
                                                   const float* __restrict__ img1, const float* __restrict__ img2,
                                                   float* __restrict__ ssim_map, float* __restrict__ dm_dmu1,
                                                   float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
@@ -42,8 +69,10 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
   __shared__ float sx[SH][SH + 1], sy[SH][SH + 1];
   __shared__ float hm[5][SH][ST + 1];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
-  const size_t plane = (size_t)blockIdx.z * H * W;
+  const SsimTile tile = ssim_tile((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  if (!tile.valid) return;                         // block-uniform
+  const int x0 = tile.tx * ST, y0 = tile.ty * ST;
+  const size_t plane = (size_t)tile.plane * H * W;
   // halo load; (row, column) of flat index i is carried from trip to trip (i += 256 = 6 rows + 4 columns at SH = 42)
   {
     int r = tid / SH, c = tid - r * SH;
@@ -135,7 +164,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
       __syncthreads();
     }
     if (tid == 0) {
-      const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const size_t b = (size_t)tile.lin;           // (plane, y, x) order: the host adds the pairs in this fixed order
       partials[2 * b] = red[0];
       partials[2 * b + 1] = red[256];
     }
@@ -145,7 +174,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float 
 // dL/dimg1 = w*(g dm_dmu1) + 2 x (w*(g dm_dsigma1_sq)) + y (w*(g dm_dsigma12)),   g = dL/dmap
 // dL_dmap == NULL: the upstream gradient of the map is the constant g_const (mean reduction), and g_l1 * sign(img1 - img2)
 // is added (the L1 term of the fused training loss).
-__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, SsimWindow win, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, SsimWindow win, const float* __restrict__ img1,
                                                   const float* __restrict__ img2, const float* __restrict__ dL_dmap,
                                                   float g_const, float g_l1, const float* __restrict__ upstream,
                                                   const float* __restrict__ dm_dmu1,
@@ -154,8 +183,10 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, SsimWindow win, 
   __shared__ float sa[3][SH][SH + 1];
   __shared__ float hm[3][SH][ST + 1];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
-  const size_t plane = (size_t)blockIdx.z * H * W;
+  const SsimTile tile = ssim_tile((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  if (!tile.valid) return;                         // block-uniform
+  const int x0 = tile.tx * ST, y0 = tile.ty * ST;
+  const size_t plane = (size_t)tile.plane * H * W;
   if (upstream) {                                  // scalar dL/dloss lives on the device: no host round trip
     const float u = upstream[0];
     g_const *= u;
@@ -235,7 +266,7 @@ int gsr_fused_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
-  GSR_LAUNCH("ssim_fwd", k_ssim_fwd, grid, dim3(256), 0, st, H, W, C1, C2, win, img1, img2, ssim_map, dm_dmu1,
+  GSR_LAUNCH("ssim_fwd", k_ssim_fwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, C1, C2, win, img1, img2, ssim_map, dm_dmu1,
              dm_dsigma1_sq, dm_dsigma12, (float*)nullptr);
   return gsr_check(hipGetLastError(), "ssim forward launch");
 }
@@ -280,7 +311,7 @@ int gsr_fused_l1_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, fl
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
-  GSR_LAUNCH("loss_fwd", k_ssim_fwd, grid, dim3(256), 0, st, H, W, C1, C2, win, img1, img2, (float*)nullptr, dm_dmu1,
+  GSR_LAUNCH("loss_fwd", k_ssim_fwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, C1, C2, win, img1, img2, (float*)nullptr, dm_dmu1,
              dm_dsigma1_sq, dm_dsigma12, partials);
   const long long nblk = (long long)grid.x * grid.y * grid.z;
   const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
@@ -301,7 +332,7 @@ int gsr_fused_l1_ssim_backward(int32_t planes, int32_t H, int32_t W, float lambd
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
   const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
-  GSR_LAUNCH("loss_bwd", k_ssim_bwd, grid, dim3(256), 0, st, H, W, win, img1, img2, (const float*)nullptr,
+  GSR_LAUNCH("loss_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, win, img1, img2, (const float*)nullptr,
              -lambda_dssim * inv_n, (1.0f - lambda_dssim) * inv_n, upstream, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
              dL_dimg1);
   return gsr_check(hipGetLastError(), "fused loss backward launch");
@@ -319,7 +350,7 @@ int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* i
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
-  GSR_LAUNCH("ssim_bwd", k_ssim_bwd, grid, dim3(256), 0, st, H, W, win, img1, img2, dL_dmap, 0.f, 0.f,
+  GSR_LAUNCH("ssim_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, win, img1, img2, dL_dmap, 0.f, 0.f,
              (const float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
   return gsr_check(hipGetLastError(), "ssim backward launch");
 }
