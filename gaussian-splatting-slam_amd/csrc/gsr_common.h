@@ -72,7 +72,9 @@ static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 #define GSR_RADIX_SIZE 256
 #define GSR_RADIX_SUBTILES 16                    // sub-tiles of 256 keys per workgroup (chunk = 4096 keys) for large arrays
 #define GSR_RADIX_SUBTILES_SMALL 8               // chunk = 2048 keys below GSR_RADIX_SMALL_N keys: twice the workgroups, so a
+#ifndef GSR_RADIX_SMALL_N
 #define GSR_RADIX_SMALL_N (2u << 20)             // 1 M-key depth sort still puts two workgroups on every CU
+#endif
 #define GSR_RADIX_CHUNK (256 * GSR_RADIX_SUBTILES)
 
 static inline size_t gsr_scan_tmp_elems(size_t n) {
