@@ -7,15 +7,22 @@
 // window 11, sigma 1.5, zero "same" padding, C1 = 0.01^2, C2 = 0.03^2), which on MI355X costs five MIOpen grouped
 // convolutions forward plus their backward (~10.7 ms per 1080p step, profiles/r01_*) against ~0.2 ms here.
 //
-// One 256-thread workgroup per 32x32 output tile of one image plane: the (32+10)^2 halo of both images is staged in
+// One 256-thread workgroup per 32x16 output tile of one image plane (26 KB of LDS -> 6 workgroups per CU; the 32x32 tile
+// of the first version needed 42 KB, 3 per CU, and ran 17 % slower): the (32+10)x(16+10) halo of both images is staged in
 // LDS once, a horizontal 11-tap pass produces the five moments (x, y, xx, yy, xy) for 42 rows, a vertical pass
 // finishes them; everything else is per-pixel arithmetic.  HBM traffic: 8 B in + 16 B out per pixel-channel forward,
 // 24 B in + 4 B out backward.
 #include "gsr_common.h"
 
-#define ST 32           // output tile
+#define ST 32           // output tile width
+#ifndef SSIM_STY
+#define SSIM_STY 16     // output tile height (multiple of 8: a thread of the vertical pass owns SSIM_STY / 8 adjacent rows)
+#endif
+#define STY SSIM_STY
 #define SR 5            // window radius
-#define SH (ST + 2 * SR)  // 42
+#define SH (ST + 2 * SR)    // halo width  42
+#define SHY (STY + 2 * SR)  // halo height
+#define RPT (STY / 8)       // rows per thread in the vertical passes (256 threads = 32 columns x 8 row groups)
 
 struct SsimWindow { float g[11]; };
 
@@ -66,17 +73,17 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int planes, floa
                                                   float* __restrict__ ssim_map, float* __restrict__ dm_dmu1,
                                                   float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
                                                   float* __restrict__ partials) {
-  __shared__ float sx[SH][SH + 1], sy[SH][SH + 1];
-  __shared__ float hm[5][SH][ST + 1];
+  __shared__ float sx[SHY][SH + 1], sy[SHY][SH + 1];
+  __shared__ float hm[5][SHY][ST + 1];
   const int tid = threadIdx.x;
-  const SsimTile tile = ssim_tile((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  const SsimTile tile = ssim_tile((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   if (!tile.valid) return;                         // block-uniform
-  const int x0 = tile.tx * ST, y0 = tile.ty * ST;
+  const int x0 = tile.tx * ST, y0 = tile.ty * STY;
   const size_t plane = (size_t)tile.plane * H * W;
   // halo load; (row, column) of flat index i is carried from trip to trip (i += 256 = 6 rows + 4 columns at SH = 42)
   {
     int r = tid / SH, c = tid - r * SH;
-    for (int i = tid; i < SH * SH; i += 256) {
+    for (int i = tid; i < SHY * SH; i += 256) {
       const int gy = y0 + r - SR, gx = x0 + c - SR;
       float a = 0.f, b = 0.f;
       if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int planes, floa
   __syncthreads();
   // horizontal pass: SH rows x ST columns, FOUR adjacent columns per thread: the 14 taps they share are read from LDS once
   // (sliding window) instead of 11 per output
-  for (int i = tid; i < SH * (ST / 4); i += 256) {
+  for (int i = tid; i < SHY * (ST / 4); i += 256) {
     const int r = i / (ST / 4), c0 = (i - r * (ST / 4)) * 4;
     float xa[14], ya[14];
 #pragma unroll
@@ -112,14 +119,14 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int planes, floa
   // vertical pass + SSIM: each thread owns column c and FOUR adjacent rows (14 shared taps per moment)
   float acc_ssim = 0.f, acc_l1 = 0.f;
   {
-    const int c = tid & (ST - 1), r0 = (tid / ST) * 4;
-    float col[5][14];
+    const int c = tid & (ST - 1), r0 = (tid / ST) * RPT;
+    float col[5][RPT + 10];
 #pragma unroll
     for (int q = 0; q < 5; q++)
 #pragma unroll
-      for (int k = 0; k < 14; k++) col[q][k] = hm[q][r0 + k][c];
+      for (int k = 0; k < RPT + 10; k++) col[q][k] = hm[q][r0 + k][c];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < RPT; j++) {
       const int r = r0 + j;
       const int gy = y0 + r, gx = x0 + c;
       if (gy >= H || gx >= W) continue;
@@ -180,12 +187,12 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, Ssim
                                                   const float* __restrict__ dm_dmu1,
                                                   const float* __restrict__ dm_dsigma1_sq,
                                                   const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
-  __shared__ float sa[3][SH][SH + 1];
-  __shared__ float hm[3][SH][ST + 1];
+  __shared__ float sa[3][SHY][SH + 1];
+  __shared__ float hm[3][SHY][ST + 1];
   const int tid = threadIdx.x;
-  const SsimTile tile = ssim_tile((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  const SsimTile tile = ssim_tile((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   if (!tile.valid) return;                         // block-uniform
-  const int x0 = tile.tx * ST, y0 = tile.ty * ST;
+  const int x0 = tile.tx * ST, y0 = tile.ty * STY;
   const size_t plane = (size_t)tile.plane * H * W;
   if (upstream) {                                  // scalar dL/dloss lives on the device: no host round trip
     const float u = upstream[0];
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, Ssim
     g_l1 *= u;
   }
   int lr = tid / SH, lc = tid - lr * SH;             // (row, column) of the flat halo index, carried incrementally
-  for (int i = tid; i < SH * SH; i += 256) {
+  for (int i = tid; i < SHY * SH; i += 256) {
     const int r = lr, c = lc;
     lr += 256 / SH; lc += 256 % SH;
     if (lc >= SH) { lc -= SH; lr++; }
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, Ssim
     sa[0][r][c] = a; sa[1][r][c] = b; sa[2][r][c] = d;
   }
   __syncthreads();
-  for (int i = tid; i < SH * (ST / 4); i += 256) {           // horizontal pass, 4 adjacent columns per thread
+  for (int i = tid; i < SHY * (ST / 4); i += 256) {           // horizontal pass, 4 adjacent columns per thread
     const int r = i / (ST / 4), c0 = (i - r * (ST / 4)) * 4;
     float v0[14], v1[14], v2[14];
 #pragma unroll
@@ -227,14 +234,14 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, Ssim
   }
   __syncthreads();
   {                                                            // vertical pass, 4 adjacent rows per thread
-    const int c = tid & (ST - 1), r0 = (tid / ST) * 4;
-    float col[3][14];
+    const int c = tid & (ST - 1), r0 = (tid / ST) * RPT;
+    float col[3][RPT + 10];
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
-      for (int k = 0; k < 14; k++) col[q][k] = hm[q][r0 + k][c];
+      for (int k = 0; k < RPT + 10; k++) col[q][k] = hm[q][r0 + k][c];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < RPT; j++) {
       const int gy = y0 + r0 + j, gx = x0 + c;
       if (gy >= H || gx >= W) continue;
       float t0 = 0.f, t1 = 0.f, t2 = 0.f;
@@ -265,7 +272,7 @@ int gsr_fused_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float
   if (planes == 0) return 0;
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   GSR_LAUNCH("ssim_fwd", k_ssim_fwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, C1, C2, win, img1, img2, ssim_map, dm_dmu1,
              dm_dsigma1_sq, dm_dsigma12, (float*)nullptr);
   return gsr_check(hipGetLastError(), "ssim forward launch");
@@ -275,29 +282,32 @@ int gsr_fused_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float
 // Forward writes the three dm_* maps and per-block partial sums partials[2*nblocks] (ssim sum, L1 sum);
 // gsr_fused_loss_blocks() gives nblocks.  The caller adds the partials (in index order) and forms the scalar.
 int64_t gsr_fused_loss_blocks(int32_t planes, int32_t H, int32_t W) {
-  return (int64_t)((W + ST - 1) / ST) * ((H + ST - 1) / ST) * planes;
+  return (int64_t)((W + ST - 1) / ST) * ((H + STY - 1) / STY) * planes;
 }
 
 // one workgroup adds the per-block partial sums in a fixed order and forms the scalar loss
-__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ partials, long long nblk, float lambda,
-                                                       float inv_n, float* __restrict__ loss) {
-  __shared__ float red[512];
+#define LOSS_FIN_THREADS 1024
+__global__ __launch_bounds__(LOSS_FIN_THREADS) void k_loss_finalize(const float* __restrict__ partials, long long nblk,
+                                                                    float lambda, float inv_n, float* __restrict__ loss) {
+  __shared__ float red[2 * LOSS_FIN_THREADS];
+  const float2* pairs = reinterpret_cast<const float2*>(partials);   // (ssim sum, L1 sum) per tile, 8-B aligned
   float a = 0.f, b = 0.f;
-  for (long long i = threadIdx.x; i < nblk; i += 256) {
-    a += partials[2 * i];
-    b += partials[2 * i + 1];
+  for (long long i = threadIdx.x; i < nblk; i += LOSS_FIN_THREADS) {
+    const float2 v = pairs[i];
+    a += v.x;
+    b += v.y;
   }
   red[threadIdx.x] = a;
-  red[256 + threadIdx.x] = b;
+  red[LOSS_FIN_THREADS + threadIdx.x] = b;
   __syncthreads();
-  for (int sft = 128; sft > 0; sft >>= 1) {
+  for (int sft = LOSS_FIN_THREADS / 2; sft > 0; sft >>= 1) {          // fixed tree: deterministic
     if ((int)threadIdx.x < sft) {
       red[threadIdx.x] += red[threadIdx.x + sft];
-      red[256 + threadIdx.x] += red[256 + threadIdx.x + sft];
+      red[LOSS_FIN_THREADS + threadIdx.x] += red[LOSS_FIN_THREADS + threadIdx.x + sft];
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) loss[0] = (1.0f - lambda) * (red[256] * inv_n) + lambda * (1.0f - red[0] * inv_n);
+  if (threadIdx.x == 0) loss[0] = (1.0f - lambda) * (red[LOSS_FIN_THREADS] * inv_n) + lambda * (1.0f - red[0] * inv_n);
 }
 
 int gsr_fused_l1_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float C2, float lambda_dssim,
@@ -310,12 +320,12 @@ int gsr_fused_l1_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, fl
   }
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   GSR_LAUNCH("loss_fwd", k_ssim_fwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, C1, C2, win, img1, img2, (float*)nullptr, dm_dmu1,
              dm_dsigma1_sq, dm_dsigma12, partials);
   const long long nblk = (long long)grid.x * grid.y * grid.z;
   const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
-  GSR_LAUNCH("loss_finalize", k_loss_finalize, dim3(1), dim3(256), 0, st, (const float*)partials, nblk, lambda_dssim,
+  GSR_LAUNCH("loss_finalize", k_loss_finalize, dim3(1), dim3(LOSS_FIN_THREADS), 0, st, (const float*)partials, nblk, lambda_dssim,
              inv_n, loss);
   return gsr_check(hipGetLastError(), "fused loss forward launch");
 }
@@ -330,7 +340,7 @@ int gsr_fused_l1_ssim_backward(int32_t planes, int32_t H, int32_t W, float lambd
   }
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
   GSR_LAUNCH("loss_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, win, img1, img2, (const float*)nullptr,
              -lambda_dssim * inv_n, (1.0f - lambda_dssim) * inv_n, upstream, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
@@ -349,7 +359,7 @@ int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* i
   if (planes == 0) return 0;
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   GSR_LAUNCH("ssim_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, win, img1, img2, dL_dmap, 0.f, 0.f,
              (const float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
   return gsr_check(hipGetLastError(), "ssim backward launch");
