@@ -275,7 +275,8 @@ int gsr_forward_shade(const gsr_settings* s, const gsr_gaussians* g, void* geome
 
 static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
                                size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
-                               float* out_color, float* out_invdepth, bool shade_late, hipEvent_t sh_ready, void* stream) {
+                               float* out_color, float* out_invdepth, bool for_backward, bool shade_late,
+                               hipEvent_t sh_ready, void* stream) {
   int rc = validate(s, g);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -299,10 +300,18 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   } else {
     gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, st);
     if ((rc = debug_sync(s, st, "emit instances"))) return rc;
-    const int where = gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a),
-                                           (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.val_b),
-                                           /*vals_iota=*/true, R, tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st,
-                                           (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(bin + BL.point_list));
+    // With a backward to follow, the sort carries (emission slot, Gaussian id): the slot of every list position is where the
+    // backward stores that instance's gradient record.  A forward-only render (torch.no_grad) needs the ids alone: they
+    // become the one sorted value (same ping-pong parity, so the list ends up in the same place), 8 B less per key and pass.
+    const int where =
+        for_backward
+            ? gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a), (uint32_t*)(bin + BL.key_b),
+                                   (uint32_t*)(bin + BL.val_b), /*vals_iota=*/true, R, tile_bits(tiles),
+                                   (uint32_t*)(bin + BL.radix_tmp), st, (uint32_t*)(bin + BL.gauss_of_slot),
+                                   (uint32_t*)(bin + BL.point_list))
+            : gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
+                                   (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.point_list), /*vals_iota=*/false, R,
+                                   tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st);
     if (where != tile_sort_result_buffer(tiles)) { gsr_set_error("internal: tile sort buffer parity"); return GSR_ERR_HIP; }
     if ((rc = debug_sync(s, st, "tile sort"))) return rc;
     const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
@@ -326,18 +335,16 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
 int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
                        size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
                        float* out_color, float* out_invdepth, int32_t for_backward, void* stream) {
-  (void)for_backward;
   return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, num_rendered, image_state, image_bytes,
-                             out_color, out_invdepth, false, nullptr, stream);
+                             out_color, out_invdepth, for_backward != 0, false, nullptr, stream);
 }
 
 int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
                              size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
                              float* out_color, float* out_invdepth, int32_t for_backward, void* sh_ready_event,
                              void* stream) {
-  (void)for_backward;
   return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, num_rendered, image_state, image_bytes,
-                             out_color, out_invdepth, true, (hipEvent_t)sh_ready_event, stream);
+                             out_color, out_invdepth, for_backward != 0, true, (hipEvent_t)sh_ready_event, stream);
 }
 
 int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,

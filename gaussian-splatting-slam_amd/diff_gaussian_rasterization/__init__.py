@@ -101,7 +101,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                raster_settings, raw_activations=False):
+                raster_settings, raw_activations=False, for_backward=True):
         lib = _C.lib()
         raw_activations = bool(raw_activations) and cov3D_precomp is None
         if not means3D.is_cuda:
@@ -114,7 +114,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         dc, sh, colors_precomp = _f32c(dc), _f32c(sh), _f32c(colors_precomp)
         opacities, scales, rotations, cov3D_precomp = _f32c(opacities), _f32c(scales), _f32c(rotations), \
             _f32c(cov3D_precomp)
-        needs_grad = any(ctx.needs_input_grad)   # all False under torch.no_grad() (reference render.py:49)
+        # (inside forward() grad mode is always off and needs_input_grad ignores an outer torch.no_grad(): whether a backward
+        # can follow is decided by the caller, rasterize_gaussians(), and arrives as `for_backward`)
+        needs_grad = bool(for_backward)
 
         with torch.cuda.device(dev):
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -207,13 +209,17 @@ class _RasterizeGaussians(torch.autograd.Function):
                         _dump("snapshot_bw.dump", rs, means3D, dc, sh, colors_precomp, opacities, scales, rotations,
                               cov3D_precomp, grad_color, grad_invdepth, radii)
                     raise
-        return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None)
+        return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, raw_activations=False):
+    # forward-only render (torch.no_grad(), reference render.py:49, or no input that requires grad): the library then skips
+    # what only a backward would need
+    tensors = (means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+    for_backward = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
     return _RasterizeGaussians.apply(means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, raw_activations)
+                                     cov3Ds_precomp, raster_settings, raw_activations, for_backward)
 
 
 class GaussianRasterizer(nn.Module):

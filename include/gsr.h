@@ -123,7 +123,8 @@ int gsr_forward_shade(const gsr_settings* s, const gsr_gaussians* g, void* geome
 
 /* Forward, phase 2: instance emission, tile sort, tile ranges and 16x16-tile alpha compositing.
  * Writes out_color[3,H,W] and out_invdepth[1,H,W] (reference :90,:101 `rendered_image`, `depth_image`).
- * `for_backward` != 0 additionally records what gsr_backward needs in the state buffers. */
+ * `for_backward` != 0 additionally records what gsr_backward needs in the state buffers (the emission slot of every list
+ * position rides through the tile sort); 0 = forward-only render, a gsr_backward on these buffers is then undefined. */
 int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
                        void* binning_state, size_t binning_bytes, int64_t num_rendered, void* image_state,
                        size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,

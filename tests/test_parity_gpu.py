@@ -365,6 +365,25 @@ def test_config4_code_path_small():
     check_grads(out, ref)
 
 
+def test_forward_only_render_is_bit_identical_to_training_forward():
+    """Under torch.no_grad() the tile sort carries the Gaussian ids alone (no emission slots for a backward that cannot
+    follow): same images, radii and inverse depth, bit for bit, as the gradient-enabled forward."""
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import GaussianModel
+    raw, cam = small_scene(P=3000, W=200, H=120)
+    cam.to("cuda")
+    model = GaussianModel.from_raw(raw.to("cuda"))
+    bg = torch.tensor([0.2, 0.4, 0.1], device="cuda")
+    for aa in (False, True):
+        pipe = PipelineParams(antialiasing=aa)
+        a = render(cam, model, pipe, bg, separate_sh=True)
+        with torch.no_grad():
+            b = render(cam, model, pipe, bg, separate_sh=True)
+        assert not b["render"].requires_grad
+        assert torch.equal(a["render"].detach(), b["render"]) and torch.equal(a["depth"].detach(), b["depth"])
+        assert torch.equal(a["radii"], b["radii"])
+
+
 def test_low_level_C_call_forms():
     """`_C.rasterize_gaussians` / `_C.rasterize_gaussians_backward` / `_C.mark_visible` (call forms of the published extension,
     SURVEY 8b) give the same numbers as the GaussianRasterizer path."""
