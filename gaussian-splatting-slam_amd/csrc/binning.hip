@@ -14,7 +14,9 @@
 // emission slots form ONE contiguous range [slot0, slot0 + count): the (tile, Gaussian) pairs are assembled in LDS and then
 // written with coalesced stores (per-thread 4-B stores at scattered addresses ran at ~0.5 TB/s).  Ranges that do not fit
 // the LDS window (a few huge splats) are written directly.
+#ifndef EMIT_WINDOW
 #define EMIT_WINDOW 4096
+#endif
 __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ offsets_incl,
                                                         const float4* __restrict__ bin_rec,
