@@ -28,6 +28,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# FP32 vector issue peak: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md
+# "Wave scheduling" and the cycle-constants row `v_fma_f32 (wave64) 2 cyc (SIMD-32)`), 2.4 GHz -> 1.2288e12 wave-instr/s
+# (= the 157.3 TFLOP/s fp32 vector peak / 128 flop per wave64 FMA).  profiles/r02_valu_microbench.txt measures it on the part.
+VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2.0
 _T0 = time.time()
 
 
@@ -76,34 +80,37 @@ def build_scene(args, device, rank, world):
     return model, cams, gts, depth_gts, my_views, pipe, bg, cfg, render
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, made by
-    tools/pmc_summary.py: FETCH_SIZE x 1024 x 2 [gfx950 correction] + WRITE_SIZE x 1024, separate passes, C3 workload).
-    None when no counter data is committed for it."""
+def _pmc(kernel, cfg_key):
+    """Per-launch PMC figures of `kernel` from the committed rocprofv3 passes (profiles/pmc_latest.json, made by
+    tools/pmc_summary.py: FETCH_SIZE x 1024 x 2 [gfx950 correction] + WRITE_SIZE x 1024, separate passes) - only when they
+    were collected on THIS workload (`workload` key of the file), otherwise None: counters of one config say nothing about
+    another."""
     try:
-        data = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
+        doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
     except Exception:
         return None
-    for name, v in data.items():
+    if doc.get("workload") != cfg_key:
+        return None
+    for name, v in doc["kernels"].items():
         if name.split("<")[0] == "k_" + kernel:
-            return int(v["traffic_bytes"])
+            return v
     return None
 
 
-def pmc_valu(kernel, avg_ms):
-    """VALU issue bound of `kernel` from the committed PMC pass (SQ_INSTS_VALU, wave-level instructions per launch at the C3
-    workload): a wave64 fp32 instruction occupies its SIMD's 16 lanes for 4 cycles, so the launch cannot finish faster than
-    insts x 4 / (1024 SIMDs x 2.4 GHz).  `issue_frac` = that bound / the measured duration."""
-    try:
-        data = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
-    except Exception:
+def pmc_traffic(kernel, cfg_key):
+    v = _pmc(kernel, cfg_key)
+    return int(v["traffic_bytes"]) if v and "traffic_bytes" in v else None
+
+
+def pmc_valu(kernel, avg_ms, cfg_key):
+    """FP32 VALU issue bound of `kernel` from SQ_INSTS_VALU (wave-level instructions per launch): no schedule finishes
+    faster than insts / VALU_WAVE_INSTR_PER_S.  `issue_frac` = that bound / the measured duration (<= 1 by construction)."""
+    v = _pmc(kernel, cfg_key)
+    if not v or "valu_insts" not in v:
         return None
-    for name, v in data.items():
-        if name.split("<")[0] == "k_" + kernel and "valu_insts" in v:
-            bound_ms = v["valu_insts"] * 4.0 / (1024 * 2.4e9) * 1e3
-            return {"insts_per_launch": int(v["valu_insts"]), "issue_bound_ms": round(bound_ms, 4),
-                    "issue_frac": round(bound_ms / avg_ms, 3) if avg_ms else None}
-    return None
+    bound_ms = v["valu_insts"] / VALU_WAVE_INSTR_PER_S * 1e3
+    return {"insts_per_launch": int(v["valu_insts"]), "cycles_per_wave_instr": 2, "issue_bound_ms": round(bound_ms, 4),
+            "issue_frac": round(bound_ms / avg_ms, 3) if avg_ms else None}
 
 
 def kernel_table(prof, R, N, P, M):
@@ -114,8 +121,11 @@ def kernel_table(prof, R, N, P, M):
         "render_fwd": 44 * R + 24 * N,
         "render_bwd": 84 * R + 24 * N,
         "preprocess_bwd": P * (2 * b_in + 79) + 44 * R,
-        "emit_instances": 20 * P + 8 * R,
-        "finalize_bins": 16 * R,
+        "emit_instances": 44 * P + 8 * R,          # order, offsets, 32-B binning record, slot_start; tile id + Gaussian id out
+        "finalize_bins": 4 * R,                    # sorted tile ids in, 8 B per tile out
+        "adam_dense": 28 * (11 + 3 * M) * P,       # param, grad, two moments in; param, two moments out
+        "sum_tiles": 4 * P,
+        "densify_stats": 28 * P,
     }
     out = {}
     for name, (ms, calls) in prof.items():
@@ -196,6 +206,16 @@ def cpu_baseline(args, model, cam, gt, bg, cfg, gpu_image):
     }
 
 
+def pair_count(model, cam, bg, cfg, dgr):
+    rs = dgr.GaussianRasterizationSettings(
+        int(cam.image_height), int(cam.image_width), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
+        cam.world_view_transform, cam.full_proj_transform, cfg["deg"], cam.camera_center, False, False,
+        bool(cfg.get("antialiasing", False)))
+    sc, ro, op = model.get_raw_geometry()
+    return dgr.pair_evaluations(rs, model.get_xyz, op, shs=model.get_features_rest, dc=model.get_features_dc, scales=sc,
+                                rotations=ro, raw_activations=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,7 +245,25 @@ def main():
                     help="force the side-stream SH update on at N=1 too (default: on only for N>1, where it hides the exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--forward-mode", default=None, choices=["async", "sync"],
+                    help="rasterizer forward: non-blocking with device-side num_rendered (default) or the blocking read-back")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one process per
+    # GPU) BEFORE anything in this process touches the GPU, relay the child's stdout / exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        if torch.cuda.device_count() < args.gpus:      # (device_count does not initialise the GPU)
+            print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} visible", file=sys.stderr)
+            sys.exit(2)
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("no launcher detected: " + " ".join(cmd))
+        sys.exit(subprocess.call(cmd))
 
     torch.set_num_threads(host_threads())
     from scene_utils import init_from_env, Trainer
@@ -235,14 +273,19 @@ def main():
     if os.environ.get("BENCH_SHARE_GPU"):
         local = 0
     log(f"rank {os.environ.get('RANK', '0')} start; host threads {host_threads()} (cpu_count {os.cpu_count()})")
-    if world != args.gpus and not (world == 1 and args.gpus == 1):
+    if world != args.gpus:
         if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank number as "
+                  f"{args.gpus} GPUs", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
+    import diff_gaussian_rasterization as dgr
+    if args.forward_mode:
+        dgr.set_forward_mode(args.forward_mode)
     model, cams, gts, depth_gts, my_views, pipe, bg, cfg, render = build_scene(args, device, rank, world)
     trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=args.optimizer,
                       loss=args.loss, separate_sh=not args.concat_sh, depth_targets=depth_gts,
@@ -274,12 +317,25 @@ def main():
     trainer.finish()       # an SH update handed to "the next forward" belongs to the step that produced it: flush it here ...
     barrier()
     log("warmup done")
+    alloc0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_ms = []
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
+        h0 = time.perf_counter()
         trainer.step(views_of_step(args.warmup + i))
+        marks[i + 1].record()          # per-step GPU timeline (the host runs ahead of the device: no wait in the loop)
+        host_ms.append((time.perf_counter() - h0) * 1e3)
     trainer.finish()       # ... and here, so the timed region holds exactly K complete optimizer steps
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    host_ms.sort()
+
+    def pct(v, q):
+        return round(v[min(len(v) - 1, int(q * len(v)))], 4)
+    timed_stats = dgr.call_stats(device)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -290,6 +346,12 @@ def main():
         "metric": "train_iters_per_sec", "value": round(world * k * args.steps / elapsed, 3),
         "unit": "view-iterations/s (render fwd + L1/DSSIM loss + bwd + Adam)", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        # distribution of the K timed steps on the GPU timeline (HIP events between steps) and of the host's enqueue time
+        "ms_per_step_median": pct(step_ms, 0.5), "ms_per_step_p10": pct(step_ms, 0.1), "ms_per_step_p90": pct(step_ms, 0.9),
+        "host_ms_per_step_median": pct(host_ms, 0.5), "host_ms_per_step_p90": pct(host_ms, 0.9),
+        "device_allocs_in_timed_region": int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - alloc0),
+        "forward_mode": {"mode": dgr.forward_mode(), "async_frames": timed_stats["async_frames"],
+                         "sync_frames": timed_stats["sync_frames"], "overflow_frames": timed_stats["overflow_frames"]},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {P} Gaussians, SH degree {cfg['deg']}, "
                                f"{W}x{H}, {len(cams)} views, one view per rank per step, all-reduce of "
@@ -323,12 +385,11 @@ def main():
     if not args.no_kernel_profile:
         lib.gsr_profile_enable(1)
         lib.gsr_profile_reset()
-        import diff_gaussian_rasterization as dgr
         nprof = max(3, min(10, args.steps))
         Rs = []
         for i in range(nprof):
             trainer.step(view_at(i))
-            Rs.append(dgr.last_call_stats["num_rendered"])   # measured R of each profiled view
+            Rs.append(dgr.call_stats(device)["num_rendered"])   # measured R of each profiled view (waits for the count)
         trainer.finish()
         torch.cuda.synchronize()
         prof = _C.profile_read()
@@ -337,17 +398,36 @@ def main():
         kt = kernel_table(prof, R, W * H, int(model.get_xyz.shape[0]), M)
         result["num_rendered_avg"] = int(R)
         result["kernels"] = kt
+        result["kernel_ms_sum"] = round(sum(v["avg_ms"] * v["calls"] for v in kt.values()) / nprof, 4)
+        # pair evaluations of the two compositing kernels (SURVEY.md 8(d) FLOP model), view 0
+        try:
+            pe = pair_count(model, cams[view_at(0)], bg, cfg, dgr)
+            for kname, key in (("render_fwd", "fwd_pairs"), ("render_bwd", "bwd_pairs")):
+                if kname in kt:
+                    kt[kname]["pairs"] = pe[key]
+                    kt[kname]["gpairs_per_s"] = round(pe[key] / (kt[kname]["avg_ms"] * 1e-3) / 1e9, 1)
+            result["pair_evaluations"] = pe
+        except Exception as e:   # an extra; never lose the headline to it
+            result["pair_evaluations"] = {"error": repr(e)}
         named = {k: v for k, v in kt.items() if "alg_bytes" in v}
         if named:
-            dom = max(named, key=lambda k: named[k]["avg_ms"])
+            dom = max(named, key=lambda k: named[k]["avg_ms"] * named[k]["calls"])
             d = named[dom]
-            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": d["gbps"], "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBS, 5),
-                                  "traffic": pmc_traffic(dom),
-                                  "avg_ms": d["avg_ms"], "alg_bytes": d["alg_bytes"],
-                                  "valu": pmc_valu(dom, d["avg_ms"]),
-                                  "note": "the render kernels are bound by FP32 VALU issue, not HBM: see `valu` "
-                                          "(DESIGN.md 4, 6); HBM fractions of the streaming kernels are in `kernels`"}
+            cfg_key = f"c{args.config}:{P}:{W}x{H}"
+            hbm = {"achieved": d["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBS, 5),
+                   "alg_bytes": d["alg_bytes"], "traffic": pmc_traffic(dom, cfg_key)}
+            valu = pmc_valu(dom, d["avg_ms"], cfg_key)
+            roof = {"kernel": dom, "avg_ms": d["avg_ms"]}
+            if dom in ("render_fwd", "render_bwd") and valu is not None:
+                # the compositing kernels stage their records through LDS and move few bytes: what bounds them is FP32
+                # VALU issue.  achieved = wave64 VALU instructions per second (SQ_INSTS_VALU of the committed PMC pass of
+                # this workload / the live HIP-event duration), peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per instruction.
+                roof.update({"bound": "valu", "achieved": round(valu["insts_per_launch"] / (d["avg_ms"] * 1e-3) / 1e9, 1),
+                             "peak": round(VALU_WAVE_INSTR_PER_S / 1e9, 1), "unit": "G wave64-VALU-instr/s",
+                             "frac": valu["issue_frac"], "traffic": hbm["traffic"], "valu": valu, "hbm": hbm})
+            else:
+                roof.update({"bound": "hbm", **hbm, "valu": valu})
+            result["roofline"] = roof
 
     log("extras done; cpu baseline next")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -16,13 +16,15 @@ void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_
                                hipStream_t);
 void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, hipStream_t);
 void gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
-                               const GsrGeomLayout&, const float4*, const gsr_grads*, hipStream_t);
+                               const GsrGeomLayout&, const float4*, uint32_t, const gsr_grads*, hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
-void gsr_launch_emit(int, int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, hipStream_t);
-void gsr_launch_finalize(uint32_t, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
+void gsr_launch_emit(int, int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, hipStream_t);
+void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
                            float*, float*, uint32_t*, hipStream_t);
+void gsr_launch_count_pairs(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, uint32_t*,
+                            hipStream_t);
 void gsr_launch_render_bwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*,
                            const float*, const uint32_t*, const float*, const float*, const uint32_t*, float4*,
                            hipStream_t);
@@ -175,8 +177,10 @@ static int validate(const gsr_settings* s, const gsr_gaussians* g) {
       return GSR_ERR_INVALID_ARGUMENT;
     }
   }
-  if (s->image_width > 65535 * GSR_TILE || s->image_height > 65535 * GSR_TILE) {
-    gsr_set_error("image too large");
+  // tile ids are sort keys and 16-bit rect coordinates: at most 65535 tiles per side and 2^24 tiles in all
+  const long long gx = ((long long)s->image_width + GSR_TILE - 1) / GSR_TILE, gy = ((long long)s->image_height + GSR_TILE - 1) / GSR_TILE;
+  if (gx > 65535 || gy > 65535 || gx * gy > (1ll << 24)) {
+    gsr_set_error("image too large: %lld x %lld tiles (limit 65535 per side, 2^24 in all)", gx, gy);
     return GSR_ERR_INVALID_ARGUMENT;
   }
   return 0;
@@ -199,18 +203,18 @@ size_t gsr_backward_scratch_bytes(int32_t P, int64_t R) {
   return gsr_align((size_t)(R < 1 ? 1 : R) * 16 * GSR_IGRAD_F4);
 }
 
-static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
-                                    size_t geometry_bytes, int32_t* radii, void* stream, bool defer_color) {
-  int rc = validate(s, g);
-  if (rc) return rc;
+// Geometry stages of the forward: projection, num_rendered (kept on the device in meta[2..3] and copied to `host_status`),
+// depth order, tile-count prefix sum.  Never waits for the device.
+static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
+                            int32_t* radii, hipStream_t st, bool defer_color, uint32_t* host_status,
+                            hipEvent_t copied /* recorded right behind the status copy, or nullptr */) {
   const int P = g->P;
-  if (P == 0) return 0;
   const GsrGeomLayout L = gsr_geom_layout(P);
   if (!geometry_state || geometry_bytes < L.total) {
     gsr_set_error("geometry state too small: %zu < %zu", geometry_bytes, L.total);
     return GSR_ERR_STATE_TOO_SMALL;
   }
-  hipStream_t st = (hipStream_t)stream;
+  int rc;
   char* geom = (char*)geometry_state;
   uint32_t* meta = (uint32_t*)(geom + L.meta);
   if ((rc = gsr_check(hipMemsetAsync(meta, 0, 64, st), "memset meta"))) return rc;
@@ -218,15 +222,14 @@ static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* 
   gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
 
-  // num_rendered (meta[2..3]) and the error flags go back to the host NOW; the depth sort
-  // and the offset scan are enqueued behind the copy and keep the GPU busy while the host waits for the two words, sizes
-  // the binning state and enqueues the binning / render stages: no idle gap at the one read-back this path needs.
+  // num_rendered (meta[2..3]) and the error flags go back to the host NOW, ahead of the depth sort and the offset scan:
+  // a blocking caller waits for the two words while the GPU still has work queued (no idle gap at the read-back), a
+  // non-blocking caller looks at them whenever it likes.
   gsr_launch_sum_tiles(P, geom, L, meta, st);
-  uint32_t* host = pinned_slot();
-  hipEvent_t ev = readback_event();
-  if (!host || !ev) { gsr_set_error("hipHostMalloc / hipEventCreate failed"); return GSR_ERR_HIP; }
-  if ((rc = gsr_check(hipMemcpyAsync(&host[0], meta, 16, hipMemcpyDeviceToHost, st), "read num_rendered"))) return rc;
-  if ((rc = gsr_check(hipEventRecord(ev, st), "record read-back event"))) return rc;
+  if (host_status &&
+      (rc = gsr_check(hipMemcpyAsync(host_status, meta, 16, hipMemcpyDeviceToHost, st), "read num_rendered")))
+    return rc;
+  if (copied && (rc = gsr_check(hipEventRecord(copied, st), "record read-back event"))) return rc;
 
   // depth order of the Gaussians (stable, so equal depths keep ascending id); 4 passes -> result in (depth_key, order)
   const int where = gsr_radix_sort_pairs((uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order),
@@ -239,7 +242,21 @@ static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* 
   gsr_scan_u32((const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.order),
                (uint32_t*)(geom + L.offsets), (size_t)P, 1, (uint32_t*)(geom + L.scan_tmp), st);
   if ((rc = debug_sync(s, st, "tile-count scan"))) return rc;
+  return 0;
+}
 
+static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
+                                    size_t geometry_bytes, int32_t* radii, void* stream, bool defer_color) {
+  int rc = validate(s, g);
+  if (rc) return rc;
+  if (g->P == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* host = pinned_slot();
+  hipEvent_t ev = readback_event();
+  if (!host || !ev) { gsr_set_error("hipHostMalloc / hipEventCreate failed"); return GSR_ERR_HIP; }
+  // the host waits on an event recorded right behind the 16-byte copy, i.e. while the depth sort and the offset scan are still
+  // queued: the GPU has ~0.1 ms of work left when the host goes on to size the binning state and enqueue the rest
+  if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, st, defer_color, host, ev))) return rc;
   if ((rc = gsr_check(hipEventSynchronize(ev), "wait for num_rendered"))) return rc;
   const unsigned long long total = (unsigned long long)host[2] | ((unsigned long long)host[3] << 32);
   if (host[1] & 1u) {
@@ -273,12 +290,18 @@ int gsr_forward_shade(const gsr_settings* s, const gsr_gaussians* g, void* geome
   return gsr_check(hipGetLastError(), "shade launch");
 }
 
+// `num_rendered` sizes the binning state and the grids (the CAPACITY); the number of instances really present is read by the
+// kernels from the geometry state (min(meta num_rendered, capacity), gsr_eff_n).  On the blocking path the two are equal.
 static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
                                size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
                                float* out_color, float* out_invdepth, bool for_backward, bool shade_late,
                                hipEvent_t sh_ready, void* stream) {
   int rc = validate(s, g);
   if (rc) return rc;
+  if (num_rendered < 0 || num_rendered > 0x7FFFFFFFll) {
+    gsr_set_error("num_rendered / capacity %lld out of range", (long long)num_rendered);
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int W = s->image_width, H = s->image_height;
   const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
@@ -295,10 +318,11 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   char* geom = (char*)geometry_state;
   char* bin = (char*)binning_state;
   char* img = (char*)image_state;
-  if (R == 0) {   // nothing to emit: every tile range is empty (otherwise the emit kernel clears them on its way)
+  const uint32_t* n_dev = g->P > 0 ? (const uint32_t*)(geom + GL.meta) + 2 : nullptr;
+  if (R == 0 || g->P == 0) {   // nothing to emit: every tile range is empty (otherwise the emit kernel clears them on its way)
     if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
   } else {
-    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, st);
+    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, st);
     if ((rc = debug_sync(s, st, "emit instances"))) return rc;
     // With a backward to follow, the sort carries (emission slot, Gaussian id): the slot of every list position is where the
     // backward stores that instance's gradient record.  A forward-only render (torch.no_grad) needs the ids alone: they
@@ -308,14 +332,14 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
             ? gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a), (uint32_t*)(bin + BL.key_b),
                                    (uint32_t*)(bin + BL.val_b), /*vals_iota=*/true, R, tile_bits(tiles),
                                    (uint32_t*)(bin + BL.radix_tmp), st, (uint32_t*)(bin + BL.gauss_of_slot),
-                                   (uint32_t*)(bin + BL.point_list))
+                                   (uint32_t*)(bin + BL.point_list), n_dev)
             : gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
                                    (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.point_list), /*vals_iota=*/false, R,
-                                   tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st);
+                                   tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st, nullptr, nullptr, n_dev);
     if (where != tile_sort_result_buffer(tiles)) { gsr_set_error("internal: tile sort buffer parity"); return GSR_ERR_HIP; }
     if ((rc = debug_sync(s, st, "tile sort"))) return rc;
     const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
-    gsr_launch_finalize((uint32_t)R, ks, bin, BL, st);
+    gsr_launch_finalize((uint32_t)R, n_dev, ks, bin, BL, st);
     if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
   }
   if (shade_late && g->P > 0) {
@@ -345,6 +369,24 @@ int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void
                              void* stream) {
   return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, num_rendered, image_state, image_bytes,
                              out_color, out_invdepth, for_backward != 0, true, (hipEvent_t)sh_ready_event, stream);
+}
+
+int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
+                      int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
+                      size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
+                      int32_t defer_color, void* sh_ready_event, uint32_t* host_status, void* stream) {
+  int rc = validate(s, g);
+  if (rc) return rc;
+  if (g->P > 0) {
+    const bool late = defer_color != 0 && !g->colors_precomp;
+    if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late, host_status,
+                               nullptr)))
+      return rc;
+    return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
+                               out_color, out_invdepth, for_backward != 0, late, (hipEvent_t)sh_ready_event, stream);
+  }
+  return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, 0, image_state, image_bytes, out_color,
+                             out_invdepth, for_backward != 0, false, nullptr, stream);
 }
 
 int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,
@@ -381,7 +423,7 @@ int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* r
                           (const uint32_t*)(bin + (tile_sort_result_buffer(tiles) ? BL.val_b : BL.val_a)), igrad, st);
     if ((rc = debug_sync(s, st, "render backward"))) return rc;
   }
-  gsr_launch_preprocess_bwd(s, g, radii, geom, GL, igrad, grads, st);
+  gsr_launch_preprocess_bwd(s, g, radii, geom, GL, igrad, (uint32_t)R, grads, st);
   if ((rc = debug_sync(s, st, "preprocess backward"))) return rc;
   return gsr_check(hipGetLastError(), "backward launch");
 }
@@ -418,6 +460,24 @@ int gsr_debug_binning_views(const void* binning_state, int32_t W, int32_t H, int
   if (point_list) *point_list = (const uint32_t*)(bin + point_list_offset(BL, tiles));
   if (ranges) *ranges = (const uint32_t*)(bin + BL.ranges);
   return 0;
+}
+
+int gsr_debug_count_pairs(const gsr_settings* s, int32_t P, const void* geometry_state, const void* binning_state,
+                          int64_t num_rendered, uint32_t* pairs, void* stream) {
+  if (!s || !geometry_state || !binning_state || !pairs || P <= 0) {
+    gsr_set_error("count_pairs: bad arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  const int W = s->image_width, H = s->image_height;
+  const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+  const int tiles = gx * gy;
+  const GsrGeomLayout GL = gsr_geom_layout(P);
+  const GsrBinLayout BL = gsr_bin_layout((size_t)num_rendered, tiles);
+  const char* geom = (const char*)geometry_state;
+  const char* bin = (const char*)binning_state;
+  gsr_launch_count_pairs(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
+                         (const float4*)(geom + GL.rec), pairs, (hipStream_t)stream);
+  return gsr_check(hipGetLastError(), "count_pairs launch");
 }
 
 int gsr_debug_image_views(const void* image_state, int32_t W, int32_t H, const float** final_T,

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
                                                         uint32_t* __restrict__ tile_key,
                                                         uint32_t* __restrict__ gauss_of_slot,
                                                         uint32_t* __restrict__ slot_start, int tiles,
-                                                        uint2* __restrict__ ranges) {
+                                                        uint2* __restrict__ ranges, uint32_t cap) {
   __shared__ uint32_t lkey[EMIT_WINDOW], lgid[EMIT_WINDOW];
   // the tile ranges are filled in after the tile sort (k_finalize_bins); tiles without instances keep this (0, 0)
   for (int t = blockIdx.x * 256 + threadIdx.x; t < tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);
@@ -54,22 +54,30 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
         const uint32_t iv = gsr_row_interval(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, y, r.x, r.z);
         const int lo = (int)(iv & 0xFFFFu), hi = (int)(iv >> 16);
         for (int x = lo; x < hi && off < end; x++) {
-          kdst[off - bias] = (uint32_t)(y * grid_x + x);
-          gdst[off - bias] = g;
+          if (staged || off < cap) {   // (direct path) slots beyond the binning state's capacity are dropped, see below
+            kdst[off - bias] = (uint32_t)(y * grid_x + x);
+            gdst[off - bias] = g;
+          }
           off++;
         }
       }
       // belt and braces: if fewer tiles passed than were counted (cannot happen with one compiled test body), park the
       // unused slots on this Gaussian's first tile with a sentinel Gaussian id that the render kernels treat as empty
       for (; off < end; off++) {
-        kdst[off - bias] = (uint32_t)(r.y * grid_x + r.x);
-        gdst[off - bias] = 0xFFFFFFFFu;
+        if (staged || off < cap) {
+          kdst[off - bias] = (uint32_t)(r.y * grid_x + r.x);
+          gdst[off - bias] = 0xFFFFFFFFu;
+        }
       }
     }
   }
   if (staged) {
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < count; i += 256) {
+    // `cap` = instances the binning state has room for.  On the blocking path cap == num_rendered and the guard never
+    // fires; on the non-blocking path (gsr_forward_async) a view with more instances than the caller's estimate loses its
+    // LAST slots, i.e. (emission runs in depth order) its farthest splats, instead of writing out of bounds.
+    const uint32_t lim = slot0 < cap ? min(count, cap - slot0) : 0u;
+    for (uint32_t i = threadIdx.x; i < lim; i += 256) {
       tile_key[slot0 + i] = lkey[i];
       gauss_of_slot[slot0 + i] = lgid[i];
     }
@@ -77,8 +85,10 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
 }
 
 // one thread per sorted instance position: tile ranges (the Gaussian id list comes out of the tile sort itself)
-__global__ __launch_bounds__(256) void k_finalize_bins(uint32_t R, const uint32_t* __restrict__ tile_sorted,
+__global__ __launch_bounds__(256) void k_finalize_bins(uint32_t cap, const uint32_t* __restrict__ n_dev,
+                                                       const uint32_t* __restrict__ tile_sorted,
                                                        uint2* __restrict__ ranges) {
+  const uint32_t R = gsr_eff_n(n_dev, cap);
   const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
   if (pos >= R) return;
   const uint32_t t = tile_sorted[pos];
@@ -95,14 +105,15 @@ __global__ __launch_bounds__(256) void k_finalize_bins(uint32_t R, const uint32_
 }
 
 void gsr_launch_emit(int P, int grid_x, int tiles, const char* geom, const GsrGeomLayout& GL, char* bin,
-                     const GsrBinLayout& BL, hipStream_t st) {
+                     const GsrBinLayout& BL, uint32_t cap, hipStream_t st) {
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
              (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
              (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start), tiles,
-             (uint2*)(bin + BL.ranges));
+             (uint2*)(bin + BL.ranges), cap);
 }
 
-void gsr_launch_finalize(uint32_t R, const uint32_t* tile_sorted, char* bin, const GsrBinLayout& BL, hipStream_t st) {
-  GSR_LAUNCH("finalize_bins", k_finalize_bins, dim3((R + 255) / 256), dim3(256), 0, st, R, tile_sorted,
+void gsr_launch_finalize(uint32_t cap, const uint32_t* n_dev, const uint32_t* tile_sorted, char* bin,
+                         const GsrBinLayout& BL, hipStream_t st) {
+  GSR_LAUNCH("finalize_bins", k_finalize_bins, dim3((cap + 255) / 256), dim3(256), 0, st, cap, n_dev, tile_sorted,
              (uint2*)(bin + BL.ranges));
 }

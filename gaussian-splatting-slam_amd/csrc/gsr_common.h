@@ -168,14 +168,27 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 // Stable LSD radix sort of (key,value) pairs on key bits [0, bits).  vals_in == nullptr means value = index.
 // Buffers ping-pong between (k0,v0) and (k1,v1); returns 0 if the result is in (k0,v0), 1 if in (k1,v1).
 // w0 / w1 (both or neither): a second 32-bit payload, input in w0, ping-ponging with w1 like the values.
+// n_dev (optional, DEVICE pointer to a 64-bit count as two u32 words): the number of keys actually present is
+// min(*n_dev, n) and is read by the kernels themselves - `n` then only sizes the grids and the tables (the capacity of a
+// caller that does not know the count on the host: gsr_forward_async).
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
-                         int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0 = nullptr, uint32_t* w1 = nullptr);
+                         int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0 = nullptr, uint32_t* w1 = nullptr,
+                         const uint32_t* n_dev = nullptr);
 
 // -------------------------------------------------------------------------------------------------
 // device helpers
 // -------------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 __device__ __forceinline__ int gsr_lane() { return threadIdx.x & 63; }
+
+// Number of instances the binning / compositing stages work on: min(num_rendered, capacity).  num_rendered lives on the
+// DEVICE (geometry state `meta[2..3]`, 64-bit, written by k_sum_tiles); `cap` is what the caller's binning state was sized
+// for (= num_rendered itself on the blocking path, an upper estimate on the non-blocking one).  n_dev == nullptr: cap.
+__device__ __forceinline__ uint32_t gsr_eff_n(const uint32_t* __restrict__ n_dev, uint32_t cap) {
+  if (!n_dev) return cap;
+  const uint32_t lo = n_dev[0], hi = n_dev[1];
+  return (hi != 0u || lo > cap) ? cap : lo;
+}
 
 // 16-B streaming (non-temporal) global accesses for data that passes through once
 typedef float gsr_f4 __attribute__((ext_vector_type(4)));

@@ -524,7 +524,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float scale_modifier, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy, int antialiasing, int raw_act,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const uint32_t* __restrict__ tiles_touched,
-    const uint32_t* __restrict__ slot_start, const float4* __restrict__ igrad, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+    const uint32_t* __restrict__ slot_start, const float4* __restrict__ igrad, const uint32_t* __restrict__ n_dev,
+    uint32_t cap, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_ddc, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dcov3D) {
@@ -562,7 +563,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float acc[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
-    const uint32_t s0 = slot_start[idx], n = tiles_touched[idx];
+    // (a non-blocking forward whose instance count exceeded the binning capacity dropped the slots >= n_eff: no records)
+    const uint32_t n_eff = gsr_eff_n(n_dev, cap);
+    const uint32_t s0 = slot_start[idx];
+    const uint32_t n = s0 < n_eff ? min(tiles_touched[idx], n_eff - s0) : 0u;
     // this Gaussian's records are contiguous (slot order): stream them, 4 records in flight per thread.
     // Summation order = slot order (deterministic).
     const float4* rows = igrad + (size_t)GSR_IGRAD_F4 * s0;
@@ -904,8 +908,8 @@ void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, in
 }
 
 void gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii,
-                               const char* geom, const GsrGeomLayout& L, const float4* igrad, const gsr_grads* gr,
-                               hipStream_t st) {
+                               const char* geom, const GsrGeomLayout& L, const float4* igrad, uint32_t cap,
+                               const gsr_grads* gr, hipStream_t st) {
   const int P = g->P;
   size_t lds = 0;
   const bool stage = can_stage_sh(s, g, &lds) && gr->dL_dshs && (((uintptr_t)gr->dL_dshs & 15) == 0);
@@ -913,7 +917,8 @@ void gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, co
   P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations, \
       g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width, s->image_height,  \
       s->tanfovx, s->tanfovy, s->antialiasing, (int)g->raw_activations, radii, (const uint8_t*)(geom + L.clamped),     \
-      (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), igrad, gr->dL_dmeans3D,      \
+      (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), igrad,                       \
+      (const uint32_t*)(geom + L.meta) + 2, cap, gr->dL_dmeans3D,                                                      \
       gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities, gr->dL_dscales, gr->dL_drotations, \
       gr->dL_dcov3D
   if (stage)

@@ -130,11 +130,15 @@ extern "C" int gsr_debug_wave_reduce(const float* in640, float* out20, void* str
 #endif
 #define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 
+// COUNT = true: the instrumented build behind gsr_debug_count_pairs (SURVEY.md 8(d) "FLOP model": pair evaluations E); it
+// additionally counts, per pixel, the list entries evaluated while the pixel was still compositing, and writes nothing else.
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                                                     const uint32_t* __restrict__ point_list,
                                                     const float4* __restrict__ rec, const float* __restrict__ bg,
                                                     float* __restrict__ out_color, float* __restrict__ out_invdepth,
-                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                    uint32_t* __restrict__ pairs) {
   __shared__ float4 s0[FWD_BATCH + 6], s1[FWD_BATCH + 6], s2[FWD_BATCH];  // +6: the prefetch may touch [n+5]
   const int tile = blockIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   float pxe = inside ? pxf : 1.0e15f;
   uint64_t live = BALLOT(inside);
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
-  uint32_t last = 0;
+  uint32_t last = 0, visited = 0;
   int vzero;   // keeps the LDS base in a VGPR (see k_render_bwd)
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   const float4 *s0v = s0 + vzero, *s1v = s1 + vzero, *s2v = s2 + vzero;
@@ -180,6 +184,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
     auto step = [&](const float4& a, const float4& b, const int j) __attribute__((always_inline)) {
       const float dx = a.x - pxe, dy = a.y - pyf;
       const float power = gsr_power2(a, b, dx, dy);
+      if (COUNT) visited += pxe < 1.0e14f ? 1u : 0u;
       // conservative wave-level reject (b.z = log2 of 1/(255 opacity), minus a margin): no lane can reach alpha >= 1/255
       if (BALLOT(power >= b.z) != 0ull) {
         const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
@@ -214,6 +219,10 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
       b1 = s1v[j + 5];
       if (j + 3 < n && live != 0ull) step(a3, b3, j + 3);
     }
+  }
+  if (COUNT) {
+    if (inside) pairs[(size_t)py * W + px] = visited;
+    return;
   }
   if (inside) {
     const size_t pix = (size_t)py * W + px;
@@ -407,8 +416,14 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
 void gsr_launch_render_fwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,
                            const uint32_t* point_list, const float4* rec, float* out_color, float* out_invdepth,
                            float* final_T, uint32_t* n_contrib, hipStream_t st) {
-  GSR_LAUNCH("render_fwd", k_render_fwd, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
-             ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib);
+  GSR_LAUNCH("render_fwd", k_render_fwd<false>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
+             ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr);
+}
+
+void gsr_launch_count_pairs(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges, const uint32_t* point_list,
+                            const float4* rec, uint32_t* pairs, hipStream_t st) {
+  hipLaunchKernelGGL(k_render_fwd<true>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x, ranges,
+                     point_list, rec, s->bg, (float*)nullptr, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, pairs);
 }
 
 void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,

@@ -141,8 +141,10 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 //          over chunks + digit totals) -> k_radix_scatter (re-read the chunk, stable rank by wave ballots, scatter).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t* __restrict__ table,
-                                                    size_t n, int shift, uint32_t mask, uint32_t nblk, int subtiles) {
+                                                    size_t n_max, const uint32_t* __restrict__ n_dev, int shift,
+                                                    uint32_t mask, uint32_t nblk, int subtiles) {
   __shared__ uint32_t hist[GSR_RADIX_SIZE];
+  const size_t n = gsr_eff_n(n_dev, (uint32_t)n_max);   // chunks beyond n still write their (all-zero) table column
   hist[threadIdx.x] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * 256 * subtiles;
@@ -202,8 +204,9 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        uint32_t* __restrict__ vals2_out,
                                                        const uint32_t* __restrict__ table_excl,
-                                                       const uint32_t* __restrict__ totals, size_t n, int shift,
-                                                       uint32_t mask, uint32_t nblk) {
+                                                       const uint32_t* __restrict__ totals, size_t n_max,
+                                                       const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
+                                                       uint32_t nblk) {
   __shared__ uint32_t wave_run[4][GSR_RADIX_SIZE];  // phase 1: keys of (wave, digit) seen so far; phase 2: the wave's base
   __shared__ uint32_t lstart[GSR_RADIX_SIZE];       // first local (sorted) position of each digit
   __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
@@ -211,6 +214,8 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
                                                     // 21 KB of LDS per workgroup instead of 36 / 52 -> 7 workgroups per CU
   __shared__ uint32_t lds4[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t n = gsr_eff_n(n_dev, (uint32_t)n_max);
+  if ((size_t)blockIdx.x * (256 * SUBTILES) >= n) return;   // block-uniform: a chunk beyond the keys present
   {
     uint32_t tot;
     const uint32_t digit_start = block_excl_scan_u32(totals[tid], &tot, lds4);   // keys with a smaller digit, whole array
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
 }
 
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
-                         int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0, uint32_t* w1) {
+                         int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0, uint32_t* w1, const uint32_t* n_dev) {
   if (n == 0 || bits <= 0) return 0;
   const uint32_t nblk = (uint32_t)gsr_radix_blocks(n);
   const int subtiles = gsr_radix_subtiles(n);
@@ -331,13 +336,13 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
     uint32_t* ko = cur ? k0 : k1;
     uint32_t* vo = cur ? v0 : v1;
     const uint32_t* vin = (shift == 0 && vals_iota) ? nullptr : vi;
-    GSR_LAUNCH("radix_hist", k_radix_hist, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, table, n, shift, mask,
-               nblk, subtiles);
+    GSR_LAUNCH("radix_hist", k_radix_hist, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, table, n, n_dev, shift,
+               mask, nblk, subtiles);
     GSR_LAUNCH("radix_rowscan", k_radix_rowscan, dim3(GSR_RADIX_SIZE), dim3(256), 0, st, table, totals, nblk);
 #define GSR_SCATTER(D, S)                                                                                              \
   GSR_LAUNCH("radix_scatter", (k_radix_scatter<D, S>), dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,         \
              (const uint32_t*)(D ? (cur ? w1 : w0) : nullptr), ko, vo, (uint32_t*)(D ? (cur ? w0 : w1) : nullptr),      \
-             (const uint32_t*)table, (const uint32_t*)totals, n, shift, mask, nblk)
+             (const uint32_t*)table, (const uint32_t*)totals, n, n_dev, shift, mask, nblk)
     if (dual) {
       if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_SCATTER(true, GSR_RADIX_SUBTILES_SMALL);
       else GSR_SCATTER(true, GSR_RADIX_SUBTILES);

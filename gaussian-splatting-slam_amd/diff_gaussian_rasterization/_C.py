@@ -64,6 +64,9 @@ EXPORTS = {
     "gsr_forward_render_shade": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
                                            C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_void_p, C.c_void_p]),
+    "gsr_forward_async": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.POINTER(gsr_grads), C.c_void_p]),
@@ -72,6 +75,8 @@ EXPORTS = {
     "gsr_debug_wave_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_binning_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p)]),
+    "gsr_debug_count_pairs": (C.c_int, [C.POINTER(gsr_settings), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                        C.c_void_p]),
     "gsr_debug_image_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p)]),
     "gsr_fused_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),
@@ -99,6 +104,7 @@ EXPORTS = {
     "gsr_profile_read": (C.c_int32, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }
 
+ABI_VERSION = 3      # GSR_ABI_VERSION of include/gsr.h
 _lib = None
 
 
@@ -120,8 +126,8 @@ def lib():
             f = getattr(l, name)         # AttributeError if a declared symbol is not exported
             f.restype = res
             f.argtypes = args
-        if l.gsr_abi_version() != 2:
-            raise GsrError(f"libgsr_hip.so ABI {l.gsr_abi_version()} != 2")
+        if l.gsr_abi_version() != ABI_VERSION:
+            raise GsrError(f"libgsr_hip.so ABI {l.gsr_abi_version()} != {ABI_VERSION}: rebuild (make -C csrc)")
         _lib = l
     return _lib
 

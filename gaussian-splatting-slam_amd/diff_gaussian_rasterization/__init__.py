@@ -18,6 +18,8 @@ import torch
 import torch.nn as nn
 
 from . import _C
+from . import _workspace as _ws
+from ._workspace import set_forward_mode, forward_mode  # noqa: F401
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -48,8 +50,13 @@ def defer_sh_until(event):
     _sh_ready_event = event
 
 
-# statistics of the most recent forward call (bench.py reports the measured num_rendered with every number)
-last_call_stats = {"num_rendered": 0}
+def call_stats(device=None, wait=True):
+    """Statistics of this device's rasterizer calls: `num_rendered` of the most recent frame whose count has arrived,
+    `overflow_frames`, `async_frames`, `sync_frames`.  wait=True first waits for the counts still in flight."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    p = _ws.pool(dev)
+    p.poll(wait=wait)
+    return dict(p.stats)
 
 
 def _dump(path, rs, *tensors):
@@ -119,48 +126,73 @@ class _RasterizeGaussians(torch.autograd.Function):
         needs_grad = bool(for_backward)
 
         with torch.cuda.device(dev):
+            pool = _ws.pool(dev)
+            pool.poll()                      # instance counts of earlier frames that have arrived meanwhile
+            ws = pool.acquire()              # state buffers of this forward (-> backward): grow-only, recycled
+            lease = _ws.Lease(pool, ws)
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)     # every entry is written by the projection kernel
             s, keep = _settings_struct(rs, dev)
             g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                               raw_activations)
-            geom = torch.empty(lib.gsr_geometry_state_bytes(P), dtype=torch.uint8, device=dev)
-            img = torch.empty(lib.gsr_image_state_bytes(W, H), dtype=torch.uint8, device=dev)
+            geom = ws.ensure_geom(lib, P)
+            img = ws.ensure_img(lib, W, H)
             global _sh_ready_event
             ev, _sh_ready_event = _sh_ready_event, None
+            split = ev is not None and colors_precomp is None
+            if ev is not None and not split:
+                torch.cuda.current_stream().wait_event(ev)
+            evh = C.c_void_p(ev.cuda_event) if split else None
+            key = (P, W, H)
+            stream = _stream()
             try:
-                if ev is not None and colors_precomp is None:
-                    # split forward: geometry stages, emission + tile sort, THEN wait for the SH update, shade, composite
-                    R = _C.check(lib.gsr_forward_prepare_geometry(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(),
-                                                                  _C.ptr(radii), _stream()))
-                    binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
-                    evh = C.c_void_p(ev.cuda_event)
-                    _C.check(lib.gsr_forward_render_shade(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning),
-                                                          binning.numel(), R, _C.ptr(img), img.numel(), _C.ptr(color),
-                                                          _C.ptr(invdepth), 1 if needs_grad else 0, evh, _stream()))
+                if _ws.forward_mode() == "async" and not rs.debug and P > 0 and key in pool.capacity:
+                    # non-blocking: the binning state is sized from the instance counts this shape has shown so far; the
+                    # count of THIS frame arrives in pinned memory and is looked at by a later call (pool.poll)
+                    R = pool.capacity[key]
+                    binning = ws.ensure_binning(lib, P, W, H, R)
+                    status = pool.status_slot()
+                    _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
+                                                   _C.ptr(binning), binning.numel(), R, _C.ptr(img), img.numel(),
+                                                   _C.ptr(color), _C.ptr(invdepth), 1 if needs_grad else 0,
+                                                   1 if split else 0, evh, C.c_void_p(status.data_ptr()), stream))
+                    done = torch.cuda.Event()
+                    done.record()
+                    pool.pending.append((done, status, R, key))
+                    pool.stats["async_frames"] += 1
                 else:
-                    if ev is not None:
-                        torch.cuda.current_stream().wait_event(ev)
-                    R = _C.check(lib.gsr_forward_prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(),
-                                                         _C.ptr(radii), _stream()))
-                    binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
-                    _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning), binning.numel(),
-                                                    R, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invdepth),
-                                                    1 if needs_grad else 0, _stream()))
+                    # blocking read-back of num_rendered (the published rasterizer's one host synchronisation): the first
+                    # frame of a shape, debug mode, or GSR_FORWARD_MODE=sync
+                    prepare = lib.gsr_forward_prepare_geometry if split else lib.gsr_forward_prepare
+                    R = _C.check(prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii), stream))
+                    pool.note(key, R)
+                    pool.stats["sync_frames"] += 1
+                    binning = ws.ensure_binning(lib, P, W, H, max(R, pool.capacity[key]))
+                    if split:
+                        # split forward: geometry stages, emission + tile sort, THEN wait for the SH update, shade, composite
+                        _C.check(lib.gsr_forward_render_shade(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning),
+                                                              binning.numel(), R, _C.ptr(img), img.numel(), _C.ptr(color),
+                                                              _C.ptr(invdepth), 1 if needs_grad else 0, evh, stream))
+                    else:
+                        _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning),
+                                                        binning.numel(), R, _C.ptr(img), img.numel(), _C.ptr(color),
+                                                        _C.ptr(invdepth), 1 if needs_grad else 0, stream))
             except _C.GsrError:
                 if rs.debug:   # reference README.md:168-169: with --debug a failing rasterizer call dumps its inputs
                     _dump("snapshot_fw.dump", rs, means3D, dc, sh, colors_precomp, opacities, scales, rotations,
                           cov3D_precomp)
                 raise
-        last_call_stats["num_rendered"] = int(R)
         ctx.raster_settings = rs
         ctx.raw_activations = raw_activations
-        ctx.num_rendered = R
+        ctx.num_rendered = R                 # what the binning state was laid out for (the count itself, or the capacity)
         ctx.has = (dc is not None, sh is not None, colors_precomp is not None, scales is not None,
                    cov3D_precomp is not None)
-        ctx.save_for_backward(means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
-                              geom, binning, img)
+        if needs_grad:
+            ctx.lease = lease                # the state buffers stay this ctx's until it dies
+        else:
+            lease.release()                  # forward-only: later work on this stream may reuse them at once
+        ctx.save_for_backward(means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)     # an unused inverse-depth output reaches backward as None, not as zeros
         return color, radii, invdepth
@@ -168,8 +200,11 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_invdepth):
         lib = _C.lib()
-        (means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, geom, binning,
-         img) = ctx.saved_tensors
+        (means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii) = ctx.saved_tensors
+        ws = ctx.lease.ws
+        if ws is None:
+            raise _C.GsrError("the rasterizer's forward state is gone (backward called twice without retain_graph?)")
+        geom, binning, img = ws.geom, ws.binning, ws.img
         rs = ctx.raster_settings
         R = ctx.num_rendered
         dev = means3D.device
@@ -194,10 +229,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_rot = like(rotations, P, 4)
             d_cov = like(cov3D_precomp, P, 6)
             if P > 0:
+                cur = torch.cuda.current_stream()
+                if ws.stream is not None and ws.stream != cur:
+                    cur.wait_stream(ws.stream)
                 s, keep = _settings_struct(rs, dev)
                 g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                   ctx.raw_activations)
-                scratch = torch.empty(lib.gsr_backward_scratch_bytes(P, R), dtype=torch.uint8, device=dev)
+                scratch = ws.ensure_scratch(lib, P, R)
                 gr = _C.gsr_grads(*[None if t is None else t.data_ptr() for t in
                                     (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov)])
                 try:
@@ -209,6 +247,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                         _dump("snapshot_bw.dump", rs, means3D, dc, sh, colors_precomp, opacities, scales, rotations,
                               cov3D_precomp, grad_color, grad_invdepth, radii)
                     raise
+                ws.stream = cur
         return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None, None)
 
 
@@ -220,6 +259,40 @@ def rasterize_gaussians(means3D, means2D, dc, sh, colors_precomp, opacities, sca
     for_backward = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
     return _RasterizeGaussians.apply(means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, raw_activations, for_backward)
+
+
+def pair_evaluations(raster_settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                     cov3D_precomp=None, dc=None, raw_activations=False):
+    """Pixel-Gaussian pair evaluations of one view (SURVEY.md 8(d) "FLOP model"), for the bench's pairs/s figures:
+    {"num_rendered", "fwd_pairs": list entries evaluated by the compositing forward summed over pixels (instrumented build of
+    the forward kernel), "bwd_pairs": sum of n_contrib (the backward replays entries 1..n_contrib of every pixel)}."""
+    lib = _C.lib()
+    rs = raster_settings
+    dev = means3D.device
+    P, H, W = int(means3D.shape[0]), int(rs.image_height), int(rs.image_width)
+    t = [_f32c(x.detach()) if x is not None else None for x in
+         (means3D, dc, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)]
+    with torch.no_grad(), torch.cuda.device(dev):
+        s, keep = _settings_struct(rs, dev)
+        g = _gauss_struct(P, *t, raw_activations and cov3D_precomp is None)
+        geom = torch.empty(lib.gsr_geometry_state_bytes(P), dtype=torch.uint8, device=dev)
+        img = torch.empty(lib.gsr_image_state_bytes(W, H), dtype=torch.uint8, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        color = torch.empty(3, H, W, device=dev)
+        invd = torch.empty(1, H, W, device=dev)
+        R = _C.check(lib.gsr_forward_prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii), _stream()))
+        binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
+        _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning), binning.numel(), R,
+                                        _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invd), 1, _stream()))
+        pairs = torch.zeros(H * W, dtype=torch.int32, device=dev)
+        _C.check(lib.gsr_debug_count_pairs(C.byref(s), P, _C.ptr(geom), _C.ptr(binning), R, _C.ptr(pairs), _stream()))
+        pT, pN = C.c_void_p(), C.c_void_p()
+        lib.gsr_debug_image_views(_C.ptr(img), W, H, C.byref(pT), C.byref(pN))
+        off = pN.value - img.data_ptr()
+        n_contrib = img[off:off + 4 * H * W].view(torch.int32)
+        out = {"num_rendered": int(R), "fwd_pairs": int(pairs.sum(dtype=torch.int64).item()),
+               "bwd_pairs": int(n_contrib.sum(dtype=torch.int64).item())}
+    return out
 
 
 class GaussianRasterizer(nn.Module):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 
 enum {
   GSR_OK = 0,
@@ -139,7 +139,25 @@ int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void
                              size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
                              void* sh_ready_event, void* stream);
 
-/* Backward of the calls above.  dL_dinvdepth may be NULL (treated as zero). */
+/* Non-blocking forward (phase 1 + phase 2 in one call, NO wait for the device): for callers that keep grow-only state
+ * buffers and cannot afford the reference rasterizer's one host read-back per frame (a SLAM / training loop enqueues several
+ * frames ahead).  The binning state is sized by the caller for `capacity` instances (gsr_binning_state_bytes(.., capacity));
+ * num_rendered stays on the device and every later stage reads min(num_rendered, capacity) from there.  If a frame has MORE
+ * instances than `capacity`, the surplus - emitted last, i.e. its farthest splats - is dropped for that frame (never an
+ * out-of-bounds access); the caller learns it from `host_status` and grows its buffers for the next frame.
+ *   host_status: NULL or 4 words of PINNED host memory, filled asynchronously on `stream` once the projection has run:
+ *                [0] reserved, [1] bit 0 = a prefiltered point failed the near-plane test, [2],[3] = num_rendered (lo, hi).
+ *                Read it after an event recorded behind this call has completed.
+ *   defer_color / sh_ready_event: as gsr_forward_prepare_geometry + gsr_forward_render_shade (0 / NULL: fused colour pass).
+ * The matching gsr_backward takes `capacity` as its num_rendered.  Same kernels, same results as the blocking pair whenever
+ * num_rendered <= capacity. */
+int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
+                      int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
+                      size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
+                      int32_t defer_color, void* sh_ready_event, uint32_t* host_status, void* stream);
+
+/* Backward of the calls above.  dL_dinvdepth may be NULL (treated as zero).  `num_rendered`: the value gsr_forward_prepare
+ * returned (and gsr_forward_render was given), or the `capacity` given to gsr_forward_async. */
 int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii,
                  const void* geometry_state, const void* binning_state, const void* image_state,
                  int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth,
@@ -157,6 +175,11 @@ int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float*
 int gsr_debug_wave_reduce(const float* in640, float* out20, void* stream);
 int gsr_debug_binning_views(const void* binning_state, int32_t image_width, int32_t image_height,
                             int64_t num_rendered, const uint32_t** point_list, const uint32_t** ranges);
+/* Pair evaluations of the compositing forward (SURVEY.md 8(d) "FLOP model"): pairs[H*W] (uint32) = per pixel, the number of
+ * list entries evaluated while the pixel was still compositing, counted by an instrumented build of the forward kernel on the
+ * state buffers of a finished forward.  (The backward's count is the sum of n_contrib: it replays entries 1..n_contrib.) */
+int gsr_debug_count_pairs(const gsr_settings* s, int32_t P, const void* geometry_state, const void* binning_state,
+                          int64_t num_rendered, uint32_t* pairs, void* stream);
 int gsr_debug_image_views(const void* image_state, int32_t image_width, int32_t image_height,
                           const float** final_T, const uint32_t** n_contrib);
 

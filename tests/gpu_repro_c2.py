@@ -17,5 +17,5 @@ for i, cam in enumerate(cams):
     with torch.no_grad():
         pkg = render(cam, model, PipelineParams(), bg)
     torch.cuda.synchronize()
-    print(f"view {i}: R={dgr.last_call_stats['num_rendered']} visible={int(pkg['visibility_filter'].sum())} "
+    print(f"view {i}: R={dgr.call_stats()["num_rendered"]} visible={int(pkg['visibility_filter'].sum())} "
           f"max radius={int(pkg['radii'].max())} {1e3*(time.time()-t0):.1f} ms", flush=True)

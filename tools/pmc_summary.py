@@ -2,7 +2,10 @@
 """Summarises rocprofv3 --pmc counter_collection CSVs (one directory per pass) into profiles/<name>.csv and
 profiles/pmc_latest.json (read by bench.py for roofline.traffic).
 
-    python tools/pmc_summary.py <out_name> <pass_dir> [<pass_dir> ...]
+    python tools/pmc_summary.py <out_name> <workload> <pass_dir> [<pass_dir> ...]
+
+<workload> = the key bench.py forms for the run the counters were collected on, "c<config>:<P>:<W>x<H>" (e.g.
+c3:1000000:1920x1080); bench.py uses the counters only for that workload.
 
 Traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from separate passes;
 bytes = FETCH_SIZE*1024*2 (gfx950 reports exactly half of a wide coalesced read stream) + WRITE_SIZE*1024.
@@ -17,7 +20,7 @@ import sys
 
 
 def main():
-    name, dirs = sys.argv[1], sys.argv[2:]
+    name, workload, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
@@ -46,7 +49,7 @@ def main():
         w.writeheader()
         for r in rows:
             w.writerow({f: r.get(f, "") for f in fields})
-    json.dump({"source": name + ".csv", "kernels": latest}, open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1)
+    json.dump({"source": name + ".csv", "workload": workload, "kernels": latest}, open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1)
     print("wrote", name + ".csv", "and pmc_latest.json for", len(rows), "kernels")
 
 
