@@ -143,7 +143,7 @@ static int tile_bits(int tiles) {
   return b;
 }
 // which ping-pong buffer holds the tile-sorted (key, slot) arrays: one swap per 8-bit pass
-static int tile_sort_result_buffer(int tiles) { return ((tile_bits(tiles) + GSR_RADIX_BITS - 1) / GSR_RADIX_BITS) & 1; }
+static int tile_sort_result_buffer(int tiles) { return gsr_radix_passes(tile_bits(tiles)) & 1; }
 // the Gaussian-id list rides through the tile sort as a second payload, ping-ponging gauss_of_slot <-> point_list
 static size_t point_list_offset(const GsrBinLayout& BL, int tiles) {
   return tile_sort_result_buffer(tiles) ? BL.point_list : BL.gauss_of_slot;
@@ -217,7 +217,9 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   int rc;
   char* geom = (char*)geometry_state;
   uint32_t* meta = (uint32_t*)(geom + L.meta);
-  if ((rc = gsr_check(hipMemsetAsync(meta, 0, 64, st), "memset meta"))) return rc;
+  // meta (num_rendered, flags) and, right behind it, the depth sort's digit histograms + pass tickets
+  static_assert(sizeof(uint32_t) == 4, "");
+  if ((rc = gsr_check(hipMemsetAsync(meta, 0, 256 + GSR_RADIX_HEAD_WORDS * 4, st), "memset meta"))) return rc;
 
   gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
@@ -234,7 +236,8 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   // depth order of the Gaussians (stable, so equal depths keep ascending id); 4 passes -> result in (depth_key, order)
   const int where = gsr_radix_sort_pairs((uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order),
                                          (uint32_t*)(geom + L.key_tmp), (uint32_t*)(geom + L.val_tmp),
-                                         /*vals_iota=*/true, (size_t)P, 32, (uint32_t*)(geom + L.radix_tmp), st);
+                                         /*vals_iota=*/true, (size_t)P, 32, (uint32_t*)(geom + L.radix_tmp), st, nullptr,
+                                         nullptr, nullptr, /*head_zeroed=*/true);
   if (where != 0) { gsr_set_error("internal: depth sort ended in the wrong buffer"); return GSR_ERR_HIP; }
   if ((rc = debug_sync(s, st, "depth sort"))) return rc;
 
@@ -263,8 +266,8 @@ static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* 
     gsr_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
     return GSR_ERR_PREFILTERED_CULLED;
   }
-  if (total > 0x7FFFFFFFull) {
-    gsr_set_error("num_rendered %llu does not fit 31 bits", total);
+  if (total > 0x3FFFFFFFull) {
+    gsr_set_error("num_rendered %llu does not fit 30 bits", total);
     return GSR_ERR_TOO_MANY_INSTANCES;
   }
   return (int64_t)total;
@@ -298,9 +301,9 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
                                hipEvent_t sh_ready, void* stream) {
   int rc = validate(s, g);
   if (rc) return rc;
-  if (num_rendered < 0 || num_rendered > 0x7FFFFFFFll) {
-    gsr_set_error("num_rendered / capacity %lld out of range", (long long)num_rendered);
-    return GSR_ERR_INVALID_ARGUMENT;
+  if (num_rendered < 0 || num_rendered > 0x3FFFFFFFll) {   // the tile sort counts keys in 30-bit fields (sort_scan.hip)
+    gsr_set_error("num_rendered / capacity %lld out of range (limit 2^30 - 1)", (long long)num_rendered);
+    return num_rendered < 0 ? GSR_ERR_INVALID_ARGUMENT : GSR_ERR_TOO_MANY_INSTANCES;
   }
   hipStream_t st = (hipStream_t)stream;
   const int W = s->image_width, H = s->image_height;
@@ -332,10 +335,10 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
             ? gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a), (uint32_t*)(bin + BL.key_b),
                                    (uint32_t*)(bin + BL.val_b), /*vals_iota=*/true, R, tile_bits(tiles),
                                    (uint32_t*)(bin + BL.radix_tmp), st, (uint32_t*)(bin + BL.gauss_of_slot),
-                                   (uint32_t*)(bin + BL.point_list), n_dev)
+                                   (uint32_t*)(bin + BL.point_list), n_dev, /*head_zeroed (by the emit kernel)=*/true)
             : gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
                                    (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.point_list), /*vals_iota=*/false, R,
-                                   tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st, nullptr, nullptr, n_dev);
+                                   tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st, nullptr, nullptr, n_dev, true);
     if (where != tile_sort_result_buffer(tiles)) { gsr_set_error("internal: tile sort buffer parity"); return GSR_ERR_HIP; }
     if ((rc = debug_sync(s, st, "tile sort"))) return rc;
     const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));

@@ -23,8 +23,12 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
                                                         uint32_t* __restrict__ tile_key,
                                                         uint32_t* __restrict__ gauss_of_slot,
                                                         uint32_t* __restrict__ slot_start, int tiles,
-                                                        uint2* __restrict__ ranges, uint32_t cap) {
+                                                        uint2* __restrict__ ranges, uint32_t cap,
+                                                        uint32_t* __restrict__ sort_head) {
   __shared__ uint32_t lkey[EMIT_WINDOW], lgid[EMIT_WINDOW];
+  // the tile sort that follows wants its digit histograms and pass tickets zeroed (sort_scan.hip, head_zeroed)
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < GSR_RADIX_HEAD_WORDS; i += 256) sort_head[i] = 0u;
   // the tile ranges are filled in after the tile sort (k_finalize_bins); tiles without instances keep this (0, 0)
   for (int t = blockIdx.x * 256 + threadIdx.x; t < tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);
   const int j0 = blockIdx.x * 256;
@@ -109,7 +113,7 @@ void gsr_launch_emit(int P, int grid_x, int tiles, const char* geom, const GsrGe
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
              (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
              (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start), tiles,
-             (uint2*)(bin + BL.ranges), cap);
+             (uint2*)(bin + BL.ranges), cap, (uint32_t*)(bin + BL.radix_tmp));
 }
 
 void gsr_launch_finalize(uint32_t cap, const uint32_t* n_dev, const uint32_t* tile_sorted, char* bin,

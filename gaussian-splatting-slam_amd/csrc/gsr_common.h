@@ -92,9 +92,22 @@ static inline size_t gsr_radix_blocks(size_t n) {
   const size_t chunk = (size_t)256 * gsr_radix_subtiles(n);
   return (n + chunk - 1) / chunk;
 }
+#define GSR_RADIX_MAX_PASSES 4
+// `bits` key bits are split into ceil(bits / 8) passes of (nearly) EQUAL width, low bits first: 13 tile-id bits sort as 7 + 6
+// (128 / 64 bins: per-digit runs of 32 / 64 keys leave a chunk as 128-B / 256-B pieces) rather than 8 + 5; 32 bits as 4 x 8.
+static inline __host__ __device__ int gsr_radix_passes(int bits) { return (bits + GSR_RADIX_BITS - 1) / GSR_RADIX_BITS; }
+static inline __host__ __device__ int gsr_radix_width(int bits, int pass) {
+  const int p = gsr_radix_passes(bits), q = bits / p, r = bits - q * p;     // the first r passes get q + 1 bits
+  return q + (pass < r ? 1 : 0);
+}
+static inline __host__ __device__ int gsr_radix_shift(int bits, int pass) {
+  const int p = gsr_radix_passes(bits), q = bits / p, r = bits - q * p;
+  return pass * q + (pass < r ? pass : r);
+}
+#define GSR_RADIX_HEAD_WORDS (GSR_RADIX_MAX_PASSES * GSR_RADIX_SIZE + 64)   // digit histograms of every pass + pass tickets
 static inline size_t gsr_radix_tmp_elems(size_t n) {
-  size_t tab = GSR_RADIX_SIZE * (gsr_radix_blocks(n) + 1);
-  return gsr_align(tab * 4) / 4 + gsr_scan_tmp_elems(tab);
+  // [histograms + tickets][look-back words: passes x chunks x 256]
+  return GSR_RADIX_HEAD_WORDS + (size_t)GSR_RADIX_MAX_PASSES * gsr_radix_blocks(n) * GSR_RADIX_SIZE;
 }
 
 static inline GsrGeomLayout gsr_geom_layout(size_t P) {
@@ -113,8 +126,8 @@ static inline GsrGeomLayout gsr_geom_layout(size_t P) {
   L.slot_start = o;    o += gsr_align(P * 4);
   L.clamped = o;       o += gsr_align(P);
   L.scan_tmp = o;      o += gsr_align(gsr_scan_tmp_elems(P) * 4);
+  L.meta = o;          o += 256;            // meta and the head of radix_tmp (histograms, tickets) are cleared by ONE memset
   L.radix_tmp = o;     o += gsr_align(gsr_radix_tmp_elems(P) * 4);
-  L.meta = o;          o += 256;
   L.total = o;
   return L;
 }
@@ -173,7 +186,9 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 // caller that does not know the count on the host: gsr_forward_async).
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
                          int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0 = nullptr, uint32_t* w1 = nullptr,
-                         const uint32_t* n_dev = nullptr);
+                         const uint32_t* n_dev = nullptr, bool head_zeroed = false);
+// head_zeroed: the caller guarantees that the first GSR_RADIX_HEAD_WORDS words of `tmp` are zero when the sort's first kernel
+// starts (an earlier kernel of the same stream cleared them); otherwise the sort enqueues a memset of its own.
 
 // -------------------------------------------------------------------------------------------------
 // device helpers

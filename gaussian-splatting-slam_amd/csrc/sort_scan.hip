@@ -136,95 +136,122 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// radix sort, 8-bit digits, stable.
-//   pass = k_radix_hist (per-chunk digit counts, table[digit][chunk]) -> k_radix_rowscan (per-digit exclusive scan
-//          over chunks + digit totals) -> k_radix_scatter (re-read the chunk, stable rank by wave ballots, scatter).
+// radix sort, 8-bit digits, stable, ONE kernel per pass (+ one histogram kernel per sort).
+//
+//   k_radix_hist_all  one read of the keys -> the digit histograms of EVERY pass (hist[pass][digit], LDS counters then one
+//                     global add per non-zero counter and workgroup); also zeroes the look-back table of the passes.
+//   k_radix_pass      per pass: a workgroup takes a chunk of 4096 keys by TICKET (atomic counter: a chunk's predecessors have
+//                     all started before it, whatever order the dispatcher chose), ranks its keys (as before: wave ballots,
+//                     wave-private LDS counters, chunk sorted locally in LDS), and gets "keys with this digit in earlier
+//                     chunks" by DECOUPLED LOOK-BACK instead of from a table two more kernels had to build: every chunk
+//                     publishes per digit first its own count (flag 1), later the inclusive prefix (flag 2), as ONE 32-bit
+//                     word {flag:2, count:30} written / polled with relaxed agent-scope atomics (global_store / global_load
+//                     sc1): the word is its own flag, so no fence or ordering against other data is needed
+//                     (/opt/skills/guides/MI355X_MICROARCH.md "Valid forms": an aligned granule written by ONE store).
+//                     A chunk walks back over its predecessors until it meets a flag-2 word.
+// The 18 launches of a forward's two sorts (4 + 2 passes x hist / rowscan / scatter) become 8; integer work, results are
+// bit-identical to the three-kernel form.  Counts are limited to 2^30 - 1 keys by the 30-bit field.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t* __restrict__ table,
-                                                    size_t n_max, const uint32_t* __restrict__ n_dev, int shift,
-                                                    uint32_t mask, uint32_t nblk, int subtiles) {
-  __shared__ uint32_t hist[GSR_RADIX_SIZE];
-  const size_t n = gsr_eff_n(n_dev, (uint32_t)n_max);   // chunks beyond n still write their (all-zero) table column
-  hist[threadIdx.x] = 0;
+#define GSR_LB_AGG (1u << 30)
+#define GSR_LB_INC (2u << 30)
+#define GSR_LB_VAL 0x3FFFFFFFu
+#ifndef GSR_LB_WINDOW
+#define GSR_LB_WINDOW 8
+#endif
+
+__global__ __launch_bounds__(256) void k_radix_hist_all(const uint32_t* __restrict__ keys, size_t n_max,
+                                                        const uint32_t* __restrict__ n_dev, int bits,
+                                                        uint32_t* __restrict__ hist, uint32_t* __restrict__ lookback,
+                                                        size_t lookback_words) {
+  __shared__ uint32_t lh[GSR_RADIX_MAX_PASSES * GSR_RADIX_SIZE];
+  const size_t n = gsr_eff_n(n_dev, (uint32_t)n_max);
+  const int passes = gsr_radix_passes(bits);
+  for (int i = threadIdx.x; i < passes * GSR_RADIX_SIZE; i += 256) lh[i] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * 256 * subtiles;
-#pragma unroll 4
-  for (int s = 0; s < subtiles; s++) {
-    size_t k = base + (size_t)s * 256 + threadIdx.x;
-    if (k < n) atomicAdd(&hist[(keys[k] >> shift) & mask], 1u);
+  // the look-back words of every pass start at "nothing published" (keys_in is 256-B aligned, so is the table)
+  {
+    uint4* z = reinterpret_cast<uint4*>(lookback);
+    const size_t n4 = lookback_words >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
   }
+  auto count = [&](uint32_t k) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < GSR_RADIX_MAX_PASSES; p++) {
+      if (p < passes) {
+        const uint32_t d = (k >> gsr_radix_shift(bits, p)) & ((1u << gsr_radix_width(bits, p)) - 1u);
+        atomicAdd(&lh[p * GSR_RADIX_SIZE + d], 1u);
+      }
+    }
+  };
+  const size_t n4 = n >> 2;
+  const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const uint4 q = k4[i];
+    count(q.x); count(q.y); count(q.z); count(q.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) count(keys[4 * n4 + threadIdx.x]);
   __syncthreads();
-  table[(size_t)threadIdx.x * nblk + blockIdx.x] = hist[threadIdx.x];
+  for (int i = threadIdx.x; i < passes * GSR_RADIX_SIZE; i += 256) {
+    const uint32_t c = lh[i];
+    if (c) atomicAdd(&hist[i], c);
+  }
 }
 
-// One workgroup per digit: exclusive scan of that digit's per-chunk counts (row `d` of the table) in place, row total to
-// totals[d].  Replaces a 3-launch device-wide scan of the whole table; the 256-entry scan of the totals is redone by
-// every scatter workgroup in LDS (trivial) instead of costing a launch.
-__global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ table, uint32_t* __restrict__ totals,
-                                                       uint32_t nblk) {
-  __shared__ uint32_t lds4[4];
-  uint32_t* row = table + (size_t)blockIdx.x * nblk;
-  uint32_t carry = 0;
-  for (uint32_t c0 = 0; c0 < nblk; c0 += GSR_SCAN_CHUNK) {
-    const uint32_t base = c0 + threadIdx.x * GSR_SCAN_ITEMS;
-    uint32_t v[GSR_SCAN_ITEMS];
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < GSR_SCAN_ITEMS; i++) {
-      v[i] = (base + i < nblk) ? row[base + i] : 0u;
-      s += v[i];
-    }
-    uint32_t tot;
-    uint32_t run = block_excl_scan_u32(s, &tot, lds4) + carry;
-#pragma unroll
-    for (int i = 0; i < GSR_SCAN_ITEMS; i++) {
-      if (base + i < nblk) row[base + i] = run;
-      run += v[i];
-    }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
-}
-
-// Scatter pass.  Each workgroup owns one chunk of 4096 keys; wave w owns the contiguous quarter [1024 w, 1024 (w+1)) of it,
-// 16 sub-tiles of 64 keys, so the original order is (wave, sub-tile, lane).
+// One pass.  Each workgroup owns one chunk of 256 * SUBTILES keys; wave w owns the contiguous quarter of it, SUBTILES
+// sub-tiles of 64 keys, so the original order is (wave, sub-tile, lane).
 //   phase 1  every wave ranks its own keys inside their (wave, digit) group with ballots and a wave-PRIVATE LDS counter row:
 //            no workgroup barrier in the loop (LDS operations of one wave execute in order);
-//   phase 2  one barrier, then per digit: totals over the four waves, each wave's base inside the digit, local start of the
-//            digit (block scan) - the chunk is sorted locally into LDS;
-//   phase 3  LDS is streamed out so that each digit's run lands in consecutive global addresses (64-B+ runs instead of the
-//            4-B scattered stores of a direct scatter).
-// Stable: equal digits keep (wave, sub-tile, lane) = original order.
+//   phase 2  one barrier, then per digit: totals over the four waves (published for the look-back at once), each wave's base
+//            inside the digit, local start of the digit (block scan) - the chunk is sorted locally into LDS;
+//   phase 3  look-back for the global base of every digit, then LDS is streamed out so that each digit's run lands in
+//            consecutive global addresses (64-B+ runs instead of the 4-B scattered stores of a direct scatter).
+// Stable: equal digits keep (chunk, wave, sub-tile, lane) = original order.
 // DUAL: a second 32-bit payload rides along (the tile sort carries the Gaussian id next to the emission slot, so no
 // gather by slot is needed afterwards).
-template <bool DUAL, int SUBTILES>   // chunk = 256 * SUBTILES keys; wave w owns keys [64 SUBTILES w, 64 SUBTILES (w+1))
-__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
-                                                       const uint32_t* __restrict__ vals_in,
-                                                       const uint32_t* __restrict__ vals2_in,
-                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                       uint32_t* __restrict__ vals2_out,
-                                                       const uint32_t* __restrict__ table_excl,
-                                                       const uint32_t* __restrict__ totals, size_t n_max,
-                                                       const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
-                                                       uint32_t nblk) {
+template <bool DUAL, int SUBTILES>
+__global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__ keys_in,
+                                                    const uint32_t* __restrict__ vals_in,
+                                                    const uint32_t* __restrict__ vals2_in,
+                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                    uint32_t* __restrict__ vals2_out,
+                                                    const uint32_t* __restrict__ hist /* this pass: [256] */,
+                                                    uint32_t* __restrict__ ticket, uint32_t* lookback /* [chunks][256] */,
+                                                    size_t n_max, const uint32_t* __restrict__ n_dev, int shift,
+                                                    uint32_t mask) {
   __shared__ uint32_t wave_run[4][GSR_RADIX_SIZE];  // phase 1: keys of (wave, digit) seen so far; phase 2: the wave's base
   __shared__ uint32_t lstart[GSR_RADIX_SIZE];       // first local (sorted) position of each digit
   __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
-  __shared__ uint32_t lbuf[(256 * SUBTILES)];        // ONE staging buffer, reused for keys, values (and the second payload):
-                                                    // 21 KB of LDS per workgroup instead of 36 / 52 -> 7 workgroups per CU
+  __shared__ uint32_t lbuf[(256 * SUBTILES)];       // ONE staging buffer, reused for keys, values (and the second payload)
   __shared__ uint32_t lds4[4];
+  __shared__ uint32_t s_chunk;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const size_t n = gsr_eff_n(n_dev, (uint32_t)n_max);
-  if ((size_t)blockIdx.x * (256 * SUBTILES) >= n) return;   // block-uniform: a chunk beyond the keys present
   {
-    uint32_t tot;
-    const uint32_t digit_start = block_excl_scan_u32(totals[tid], &tot, lds4);   // keys with a smaller digit, whole array
-    gbase[tid] = digit_start + table_excl[(size_t)tid * nblk + blockIdx.x];
+    // Every key has the same digit in this pass (e.g. the top byte of fp32 depths that span less than a factor of 4): the
+    // pass is the identity permutation, so the chunk is copied straight across - no ticket, no ranking, no look-back.
+    const size_t n0 = gsr_eff_n(n_dev, (uint32_t)n_max);
+    if (__syncthreads_or(hist[tid] == (uint32_t)n0 && n0 != 0)) {
+      const size_t b0 = (size_t)blockIdx.x * (256 * SUBTILES);
+      for (uint32_t i = tid; i < (uint32_t)(256 * SUBTILES) && b0 + i < n0; i += 256) {
+        keys_out[b0 + i] = keys_in[b0 + i];
+        vals_out[b0 + i] = vals_in ? vals_in[b0 + i] : (uint32_t)(b0 + i);
+        if (DUAL) vals2_out[b0 + i] = vals2_in[b0 + i];
+      }
+      return;
+    }
   }
+  if (tid == 0) s_chunk = atomicAdd(ticket, 1u);    // chunks are taken in ticket order: every predecessor is already running
 #pragma unroll
   for (int i = 0; i < 4; i++) wave_run[i][tid] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * (256 * SUBTILES);
+  const uint32_t chunk = s_chunk;
+  const size_t n = gsr_eff_n(n_dev, (uint32_t)n_max);
+  const size_t base = (size_t)chunk * (256 * SUBTILES);
+  if (base >= n) return;                            // block-uniform: a chunk beyond the keys present (nobody looks back at it)
+  uint32_t digit_start;                             // keys with a smaller digit, whole array
+  {
+    uint32_t tot;
+    digit_start = block_excl_scan_u32(hist[tid], &tot, lds4);
+  }
   const uint32_t count = (uint32_t)min((size_t)(256 * SUBTILES), n - base);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint32_t wbase = (uint32_t)w * (64 * SUBTILES);
@@ -260,11 +287,16 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     }
   }
   __syncthreads();
+  uint32_t my_count;
   {
     // per digit (thread = digit): totals over the waves, each wave's base inside the digit, local start of the digit
     const uint32_t c0 = wave_run[0][tid], c1 = wave_run[1][tid], c2 = wave_run[2][tid], c3 = wave_run[3][tid];
+    my_count = c0 + c1 + c2 + c3;
+    // publish this chunk's count of digit `tid` at once (chunk 0 knows its inclusive prefix already)
+    __hip_atomic_store(&lookback[(size_t)chunk * GSR_RADIX_SIZE + tid], (chunk == 0 ? GSR_LB_INC : GSR_LB_AGG) | my_count,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t tot;
-    lstart[tid] = block_excl_scan_u32(c0 + c1 + c2 + c3, &tot, lds4);
+    lstart[tid] = block_excl_scan_u32(my_count, &tot, lds4);
     wave_run[0][tid] = 0;
     wave_run[1][tid] = c0;
     wave_run[2][tid] = c0 + c1;
@@ -277,12 +309,54 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     const uint32_t d = rk[s] >> 16;
     rk[s] = lstart[d] + my_run[d] + (rk[s] & 0xFFFFu);
   }
-  // round 1: keys through LDS; each thread also learns the global position of the sorted positions it streams out
-  uint32_t gpos[SUBTILES];
+  // round 1: keys into LDS in sorted order
 #pragma unroll
   for (int s = 0; s < SUBTILES; s++)
     if (wbase + (uint32_t)s * 64 + lane < count) lbuf[rk[s]] = key[s];
+  // look-back (thread = digit): keys of this digit in all earlier chunks.  Every word polled belongs to a chunk whose
+  // workgroup holds an earlier ticket, i.e. is resident or finished: the wait is bounded by that workgroup's phase 1.
+  {
+    uint32_t excl = 0;
+    if (chunk != 0) {
+      // GSR_LB_WINDOW predecessors per trip, all loads in flight together: with ~1000 chunks started at once the walk back
+      // to the nearest finished prefix is tens of chunks long, and one dependent ~1 us poll per chunk made the pass slower
+      // than the three-kernel form it replaces
+      int64_t p = (int64_t)chunk - 1;
+      bool done = false;
+      uint32_t spins = 0;
+      while (!done) {
+        uint32_t v[GSR_LB_WINDOW];
+#pragma unroll
+        for (int i = 0; i < GSR_LB_WINDOW; i++)
+          v[i] = (p - i >= 0) ? __hip_atomic_load(&lookback[(size_t)(p - i) * GSR_RADIX_SIZE + tid], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : GSR_LB_INC;
+        int used = 0;
+#pragma unroll
+        for (int i = 0; i < GSR_LB_WINDOW; i++) {
+          if (!done && used == i) {
+            if ((v[i] & ~GSR_LB_VAL) != 0u) {
+              excl += v[i] & GSR_LB_VAL;
+              done = (v[i] & GSR_LB_INC) != 0u;
+              used = i + 1;
+            }
+          }
+        }
+        p -= used;                    // the first word not yet published (if any) heads the next window
+        if (!done && used < GSR_LB_WINDOW) {
+          // (bounded, like every spin should be: ~1 s; a time-out can only mean a broken protocol - it leaves a mark in
+          // the word behind the tickets, gives this chunk a wrong base and lets the grid drain instead of hanging the GPU)
+          if (++spins > (1u << 20)) { ticket[GSR_RADIX_MAX_PASSES] = 0xDEADu; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __hip_atomic_store(&lookback[(size_t)chunk * GSR_RADIX_SIZE + tid], GSR_LB_INC | (excl + my_count), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gbase[tid] = digit_start + excl;
+  }
   __syncthreads();
+  uint32_t gpos[SUBTILES];
 #pragma unroll
   for (int k = 0; k < SUBTILES; k++) {
     const uint32_t i = (uint32_t)k * 256 + tid;
@@ -320,37 +394,44 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
 }
 
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
-                         int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0, uint32_t* w1, const uint32_t* n_dev) {
+                         int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0, uint32_t* w1, const uint32_t* n_dev,
+                         bool head_zeroed) {
   if (n == 0 || bits <= 0) return 0;
   const uint32_t nblk = (uint32_t)gsr_radix_blocks(n);
   const int subtiles = gsr_radix_subtiles(n);
-  uint32_t* table = tmp;
-  uint32_t* totals = tmp + (size_t)GSR_RADIX_SIZE * nblk;     // sized by gsr_radix_tmp_elems: 256 * (nblk + 1)
+  const int passes = gsr_radix_passes(bits);
+  // tmp = [hist: MAX_PASSES x 256][tickets: 64 words][look-back: passes x chunks x 256]   (gsr_radix_tmp_elems)
+  uint32_t* hist = tmp;
+  uint32_t* tickets = tmp + GSR_RADIX_MAX_PASSES * GSR_RADIX_SIZE;
+  uint32_t* lookback = tmp + GSR_RADIX_HEAD_WORDS;
+  const size_t lb_words = (size_t)passes * nblk * GSR_RADIX_SIZE;
+  if (!head_zeroed) (void)hipMemsetAsync(tmp, 0, GSR_RADIX_HEAD_WORDS * 4, st);
   const bool dual = w0 != nullptr && w1 != nullptr;
+  const unsigned hgrid = nblk < 512u ? nblk : 512u;
+  GSR_LAUNCH("radix_hist", k_radix_hist_all, dim3(hgrid), dim3(256), 0, st, (const uint32_t*)k0, n, n_dev, bits, hist,
+             lookback, lb_words);
   int cur = 0;
-  for (int shift = 0; shift < bits; shift += GSR_RADIX_BITS) {
-    const int nb = (bits - shift) < GSR_RADIX_BITS ? (bits - shift) : GSR_RADIX_BITS;
-    const uint32_t mask = (1u << nb) - 1u;
+  for (int pass = 0; pass < passes; pass++) {
+    const int shift = gsr_radix_shift(bits, pass);
+    const uint32_t mask = (1u << gsr_radix_width(bits, pass)) - 1u;
     uint32_t* ki = cur ? k1 : k0;
     uint32_t* vi = cur ? v1 : v0;
     uint32_t* ko = cur ? k0 : k1;
     uint32_t* vo = cur ? v0 : v1;
-    const uint32_t* vin = (shift == 0 && vals_iota) ? nullptr : vi;
-    GSR_LAUNCH("radix_hist", k_radix_hist, dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, table, n, n_dev, shift,
-               mask, nblk, subtiles);
-    GSR_LAUNCH("radix_rowscan", k_radix_rowscan, dim3(GSR_RADIX_SIZE), dim3(256), 0, st, table, totals, nblk);
-#define GSR_SCATTER(D, S)                                                                                              \
-  GSR_LAUNCH("radix_scatter", (k_radix_scatter<D, S>), dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,         \
+    const uint32_t* vin = (pass == 0 && vals_iota) ? nullptr : vi;
+#define GSR_PASS(D, S)                                                                                                 \
+  GSR_LAUNCH("radix_pass", (k_radix_pass<D, S>), dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,               \
              (const uint32_t*)(D ? (cur ? w1 : w0) : nullptr), ko, vo, (uint32_t*)(D ? (cur ? w0 : w1) : nullptr),      \
-             (const uint32_t*)table, (const uint32_t*)totals, n, n_dev, shift, mask, nblk)
+             (const uint32_t*)(hist + pass * GSR_RADIX_SIZE), tickets + pass,                                          \
+             lookback + (size_t)pass * nblk * GSR_RADIX_SIZE, n, n_dev, shift, mask)
     if (dual) {
-      if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_SCATTER(true, GSR_RADIX_SUBTILES_SMALL);
-      else GSR_SCATTER(true, GSR_RADIX_SUBTILES);
+      if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_PASS(true, GSR_RADIX_SUBTILES_SMALL);
+      else GSR_PASS(true, GSR_RADIX_SUBTILES);
     } else {
-      if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_SCATTER(false, GSR_RADIX_SUBTILES_SMALL);
-      else GSR_SCATTER(false, GSR_RADIX_SUBTILES);
+      if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_PASS(false, GSR_RADIX_SUBTILES_SMALL);
+      else GSR_PASS(false, GSR_RADIX_SUBTILES);
     }
-#undef GSR_SCATTER
+#undef GSR_PASS
     cur ^= 1;
   }
   return cur;

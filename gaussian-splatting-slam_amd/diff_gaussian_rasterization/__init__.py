@@ -147,7 +147,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             key = (P, W, H)
             stream = _stream()
             try:
-                if _ws.forward_mode() == "async" and not rs.debug and P > 0 and key in pool.capacity:
+                if _ws.forward_mode() == "async" and not rs.debug and not rs.prefiltered and P > 0 and \
+                        key in pool.capacity:
                     # non-blocking: the binning state is sized from the instance counts this shape has shown so far; the
                     # count of THIS frame arrives in pinned memory and is looked at by a later call (pool.poll)
                     R = pool.capacity[key]
@@ -163,7 +164,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                     pool.stats["async_frames"] += 1
                 else:
                     # blocking read-back of num_rendered (the published rasterizer's one host synchronisation): the first
-                    # frame of a shape, debug mode, or GSR_FORWARD_MODE=sync
+                    # frame of a shape, debug mode, prefiltered=True (its "culled point" error is raised by this very call), or
+                    # GSR_FORWARD_MODE=sync
                     prepare = lib.gsr_forward_prepare_geometry if split else lib.gsr_forward_prepare
                     R = _C.check(prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii), stream))
                     pool.note(key, R)

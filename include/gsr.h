@@ -38,7 +38,7 @@ enum {
   GSR_ERR_INVALID_ARGUMENT = -1, /* bad combination of inputs (both/neither of shs|colors_precomp ...) */
   GSR_ERR_HIP = -2,              /* a HIP runtime call failed */
   GSR_ERR_PREFILTERED_CULLED = -3, /* prefiltered=1 but a point failed the near-plane test */
-  GSR_ERR_TOO_MANY_INSTANCES = -4, /* num_rendered does not fit 31 bits */
+  GSR_ERR_TOO_MANY_INSTANCES = -4, /* num_rendered (or the capacity) exceeds 2^30 - 1 */
   GSR_ERR_STATE_TOO_SMALL = -5   /* a caller-provided state buffer is smaller than required */
 };
 
