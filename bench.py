@@ -227,7 +227,10 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--cpu-tiles", type=int, default=256)
-    ap.add_argument("--optimizer", default="hip", choices=["hip", "hip_sparse", "torch"])
+    ap.add_argument("--optimizer", default="hip_fused", choices=["hip", "hip_fused", "hip_sparse", "hip_sparse_fused", "torch"],
+                    help="hip: one-launch Adam kernel (torch.optim.Adam semantics, the reference's default optimizer); "
+                         "hip_sparse: SparseGaussianAdam (reference train.py:173-176); *_fused: the same update folded into "
+                         "the rasterizer's backward (gsr_backward_adam), bit-identical results")
     ap.add_argument("--loss", default="hip", choices=["hip", "torch"])
     ap.add_argument("--concat-sh", action="store_true",
                     help="pass torch.cat(dc, rest) as shs (separate_sh=False); default mirrors reference train.py:106 with "
@@ -243,6 +246,9 @@ def main():
                          "step's geometry stages; same results, DESIGN.md 5)")
     ap.add_argument("--overlap", action="store_true",
                     help="force the side-stream SH update on at N=1 too (default: on only for N>1, where it hides the exchange)")
+    ap.add_argument("--hi-prio", action="store_true",
+                    help="run the training loop on a high-priority stream (the side stream of --overlap stays at normal "
+                         "priority, so the small binning kernels are dispatched ahead of the bandwidth-bound SH update)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--forward-mode", default=None, choices=["async", "sync"],
@@ -312,6 +318,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.hi_prio:
+        hi = torch.cuda.Stream(device=device, priority=-1)
+        hi.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hi)
     for i in range(args.warmup):
         trainer.step(views_of_step(i))
     trainer.finish()       # an SH update handed to "the next forward" belongs to the step that produced it: flush it here ...
@@ -362,7 +372,10 @@ def main():
                    "views_per_rank_per_step": k, "overlap_comm": bool(trainer.overlap_comm),
                    "loss": "L1 + 0.2 DSSIM (" + ("HIP fused SSIM" if args.loss == "hip" else "torch conv2d SSIM") + ")",
                    "optimizer": {"hip": "Adam, one-launch HIP kernel (torch.optim.Adam semantics)",
-                                 "hip_sparse": "SparseGaussianAdam (HIP)", "torch": "torch.optim.Adam"}[args.optimizer]},
+                                 "hip_fused": "Adam (torch.optim.Adam semantics) folded into the rasterizer backward",
+                                 "hip_sparse": "SparseGaussianAdam (HIP)",
+                                 "hip_sparse_fused": "SparseGaussianAdam folded into the rasterizer backward",
+                                 "torch": "torch.optim.Adam"}[args.optimizer]},
     }
 
     # ---- untimed extras (rank 0 reports) ----

@@ -30,6 +30,8 @@ struct AdamBatch {
 template <bool SPARSE>
 __global__ __launch_bounds__(256) void k_adam(AdamBatch b, float beta1, float beta2, float omb1, float omb2, float eps,
                                               const uint8_t* __restrict__ visible) {
+  GsrAdamArgs A;     // the per-element update is the one shared with the step folded into k_preprocess_bwd (gsr_common.h)
+  A.beta1 = beta1; A.beta2 = beta2; A.omb1 = omb1; A.omb2 = omb2; A.eps = eps;
   int t = 0;
 #pragma unroll
   for (int i = 1; i < GSR_ADAM_MAX_TENSORS; i++)
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamBatch b, float beta1, float be
   float* __restrict__ V = b.v[t];
   const long long n = b.n[t];
   const int row = b.row[t];
-  const float lr = b.lr[t], step_size = b.step_size[t], inv_bc2 = b.inv_bc2_sqrt[t];
+  A.lr[0] = b.lr[t]; A.step_size[0] = b.step_size[t]; A.inv_bc2_sqrt[0] = b.inv_bc2_sqrt[t];
   const long long base = (long long)(blockIdx.x - b.block_begin[t]) * ADAM_ELEMS_PER_BLOCK;
   const bool vec_ok = (n % 4 == 0) && ((((uintptr_t)P | (uintptr_t)G | (uintptr_t)M | (uintptr_t)V) & 15) == 0);
 #pragma unroll
@@ -66,16 +68,10 @@ __global__ __launch_bounds__(256) void k_adam(AdamBatch b, float beta1, float be
       if (SPARSE) {
         if (!visible[(i0 + k) / row]) continue;
         any = true;
-        const float g = g4[k];
-        m4[k] = beta1 * m4[k] + omb1 * g;
-        v4[k] = beta2 * v4[k] + omb2 * g * g;
-        p4[k] += -lr * m4[k] / (sqrtf(v4[k]) + eps);
+        adam_elem<2>(p4[k], m4[k], v4[k], g4[k], A, 0);
       } else {
-        const float g = g4[k];
-        m4[k] = m4[k] + (g - m4[k]) * omb1;                    // torch: exp_avg.lerp_(grad, 1 - beta1)
-        v4[k] = beta2 * v4[k] + omb2 * g * g;                  // 1 - beta formed in double on the host, as torch does
-        const float denom = sqrtf(v4[k]) * inv_bc2 + eps;
-        p4[k] -= step_size * (m4[k] / denom);
+        // torch: exp_avg.lerp_(grad, 1 - beta1); 1 - beta formed in double on the host, as torch does
+        adam_elem<1>(p4[k], m4[k], v4[k], g4[k], A, 0);
       }
     }
     if (!any) continue;

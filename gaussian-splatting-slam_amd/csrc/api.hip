@@ -1,4 +1,5 @@
 // api.hip - extern "C" entry points of libgsr_hip.so (declared in include/gsr.h) and host orchestration.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,8 +16,9 @@
 void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool,
                                hipStream_t);
 void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, hipStream_t);
-void gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
-                               const GsrGeomLayout&, const float4*, uint32_t, const gsr_grads*, hipStream_t);
+int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
+                              const GsrGeomLayout&, const float4*, uint32_t, const gsr_grads*, const GsrAdamArgs*, int,
+                              hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
 void gsr_launch_emit(int, int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, hipStream_t);
 void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
@@ -392,13 +394,13 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
                              out_invdepth, for_backward != 0, false, nullptr, stream);
 }
 
-int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,
-                 const void* binning_state, const void* image_state, int64_t num_rendered, const float* dL_dcolor,
-                 const float* dL_dinvdepth, void* scratch, size_t scratch_bytes, const gsr_grads* grads,
-                 void* stream) {
+static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,
+                         const void* binning_state, const void* image_state, int64_t num_rendered, const float* dL_dcolor,
+                         const float* dL_dinvdepth, void* scratch, size_t scratch_bytes, const gsr_grads* grads,
+                         const gsr_fused_adam* opt, void* stream) {
   int rc = validate(s, g);
   if (rc) return rc;
-  if (!grads || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacities || !dL_dcolor) {
+  if (!grads || !grads->dL_dmeans2D || !dL_dcolor || (!opt && (!grads->dL_dmeans3D || !grads->dL_dopacities))) {
     gsr_set_error("backward: missing mandatory gradient buffers");
     return GSR_ERR_INVALID_ARGUMENT;
   }
@@ -426,9 +428,52 @@ int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* r
                           (const uint32_t*)(bin + (tile_sort_result_buffer(tiles) ? BL.val_b : BL.val_a)), igrad, st);
     if ((rc = debug_sync(s, st, "render backward"))) return rc;
   }
-  gsr_launch_preprocess_bwd(s, g, radii, geom, GL, igrad, (uint32_t)R, grads, st);
+  GsrAdamArgs A;
+  if (opt) {
+    float* params[6] = {(float*)g->means3D, (float*)g->dc, (float*)g->shs, (float*)g->opacities, (float*)g->scales,
+                        (float*)g->rotations};
+    for (int i = 0; i < 6; i++) {
+      const bool present = params[i] != nullptr;
+      if (present && (!opt->exp_avg[i] || !opt->exp_avg_sq[i])) {
+        gsr_set_error("backward_adam: no moments for parameter group %d", i);
+        return GSR_ERR_INVALID_ARGUMENT;
+      }
+      A.p[i] = params[i]; A.m[i] = opt->exp_avg[i]; A.v[i] = opt->exp_avg_sq[i];
+      A.lr[i] = opt->lr[i];
+      const double bc1 = 1.0 - pow(opt->beta1, (double)opt->step[i]);
+      const double bc2 = 1.0 - pow(opt->beta2, (double)opt->step[i]);
+      A.step_size[i] = opt->sparse ? 0.f : (float)((double)opt->lr[i] / bc1);
+      A.inv_bc2_sqrt[i] = opt->sparse ? 0.f : (float)(1.0 / sqrt(bc2));
+    }
+    A.beta1 = (float)opt->beta1; A.beta2 = (float)opt->beta2;
+    A.omb1 = (float)(1.0 - opt->beta1); A.omb2 = (float)(1.0 - opt->beta2);
+    A.eps = (float)opt->eps;
+  }
+  if (gsr_launch_preprocess_bwd(s, g, radii, geom, GL, igrad, (uint32_t)R, grads, opt ? &A : nullptr,
+                                opt && opt->sparse ? 2 : 1, st)) {
+    gsr_set_error("backward_adam needs the raw-parameter call form with dc / shs passed separately (raw_activations = 1, "
+                  "dc != NULL, no colors_precomp / cov3D_precomp, every stored SH coefficient active)");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
   if ((rc = debug_sync(s, st, "preprocess backward"))) return rc;
   return gsr_check(hipGetLastError(), "backward launch");
+}
+
+int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,
+                 const void* binning_state, const void* image_state, int64_t num_rendered, const float* dL_dcolor,
+                 const float* dL_dinvdepth, void* scratch, size_t scratch_bytes, const gsr_grads* grads,
+                 void* stream) {
+  return backward_impl(s, g, radii, geometry_state, binning_state, image_state, num_rendered, dL_dcolor, dL_dinvdepth,
+                       scratch, scratch_bytes, grads, nullptr, stream);
+}
+
+int gsr_backward_adam(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,
+                      const void* binning_state, const void* image_state, int64_t num_rendered, const float* dL_dcolor,
+                      const float* dL_dinvdepth, void* scratch, size_t scratch_bytes, const gsr_grads* grads,
+                      const gsr_fused_adam* opt, void* stream) {
+  if (!opt) { gsr_set_error("backward_adam: null optimizer arguments"); return GSR_ERR_INVALID_ARGUMENT; }
+  return backward_impl(s, g, radii, geometry_state, binning_state, image_state, num_rendered, dL_dcolor, dL_dinvdepth,
+                       scratch, scratch_bytes, grads, opt, stream);
 }
 
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream) {

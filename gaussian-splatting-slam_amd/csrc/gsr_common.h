@@ -158,6 +158,15 @@ static inline GsrImgLayout gsr_img_layout(size_t N) {
   return L;
 }
 
+// optimizer step folded into k_preprocess_bwd (gsr_backward_adam): kernel-side form of gsr_fused_adam
+struct GsrAdamArgs {
+  float* p[6];      // xyz, f_dc, f_rest, opacity, scaling, rotation (the rasterizer's own input arrays, updated in place)
+  float* m[6];
+  float* v[6];
+  float lr[6], step_size[6], inv_bc2_sqrt[6];
+  float beta1, beta2, omb1, omb2, eps;
+};
+
 // -------------------------------------------------------------------------------------------------
 // host-side launch helpers (api.hip owns the definitions)
 // -------------------------------------------------------------------------------------------------
@@ -203,6 +212,25 @@ __device__ __forceinline__ uint32_t gsr_eff_n(const uint32_t* __restrict__ n_dev
   if (!n_dev) return cap;
   const uint32_t lo = n_dev[0], hi = n_dev[1];
   return (hi != 0u || lo > cap) ? cap : lo;
+}
+
+// One Adam update, shared by k_adam (adam.hip) and the step folded into k_preprocess_bwd (preprocess.hip): every rounding is
+// spelled out (explicit fma / separate operations) so that both kernels produce the same bits whatever the compiler would
+// contract in their different surroundings.  ADAM = 1: torch.optim.Adam (exp_avg.lerp_, bias-corrected step, eps after the
+// corrected sqrt); ADAM = 2: the sparse optimizer of the reference's accelerated path (no bias correction).
+template <int ADAM>
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, const float g, const GsrAdamArgs& A, const int grp) {
+  const float gg = __fmul_rn(__fmul_rn(A.omb2, g), g);
+  if (ADAM == 2) {
+    m = __builtin_fmaf(A.beta1, m, __fmul_rn(A.omb1, g));
+    v = __builtin_fmaf(A.beta2, v, gg);
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-A.lr[grp], m), __fadd_rn(__fsqrt_rn(v), A.eps)));
+  } else {
+    m = __builtin_fmaf(__fsub_rn(g, m), A.omb1, m);
+    v = __builtin_fmaf(A.beta2, v, gg);
+    const float denom = __builtin_fmaf(__fsqrt_rn(v), A.inv_bc2_sqrt[grp], A.eps);
+    p = __builtin_fmaf(-A.step_size[grp], __fdiv_rn(m, denom), p);
+  }
 }
 
 // 16-B streaming (non-temporal) global accesses for data that passes through once

@@ -12,7 +12,14 @@
 // graphdeco-inria/diff-gaussian-rasterization@9c5c2028, absent from the reference tree) and the boundary
 // contract of reference gaussian_renderer/__init__.py:18-121.  SH basis / constants: reference
 // utils/sh_utils.py:26-100.  Quaternion -> R and Sigma packing: reference utils/general_utils.py:64-110.
+#include <string.h>
+
 #include "gsr_common.h"
+
+// No implicit fma contraction in this file: k_preprocess_bwd exists in three instantiations (plain, Adam folded in, sparse Adam
+// folded in) whose gradients must agree bit for bit, and what the compiler contracts depends on how a value is used further
+// down.  These kernels are HBM-bound; the few extra multiplies do not show.
+#pragma clang fp contract(off)
 
 #define SH_C0 0.28209479177387814f
 #define SH_C1 0.4886025119029199f
@@ -516,7 +523,26 @@ __global__ __launch_bounds__(256) void k_shade(int P, int deg, int sh_stride, co
 // power = -0.5(A dx^2 + C dy^2) - B dx dy:  dL/dA = -S_xx/2, dL/dB = -S_xy, dL/dC = -S_yy/2 and
 // dL/dmean2D(ndc) = (W/2)(-A S_x - B S_y), (H/2)(-C S_y - B S_x): linear in the sums, so applied once, after the gather.
 // ---------------------------------------------------------------------------------------------------
-template <bool STAGE>
+// Optimizer step folded into this kernel (gsr_backward_adam, include/gsr.h): ADAM = 1 torch.optim.Adam semantics on every row,
+// ADAM = 2 SparseGaussianAdam semantics (rows with radii == 0 untouched, no bias correction).  Same arithmetic, element for
+// element, as k_adam (adam.hip) applied to the gradients this kernel would have written - which then never travel through HBM:
+// the 59 floats per Gaussian are neither stored here nor re-read there (2 x 236 MB per step at 1 M Gaussians, SH 3).
+// the n (<= 4) consecutive elements of one Gaussian's row of a small parameter group
+template <int ADAM, int N>
+__device__ __forceinline__ void adam_row(const GsrAdamArgs& A, const int grp, const size_t idx, const float* g) {
+  float* P = A.p[grp] + N * idx;
+  float* M = A.m[grp] + N * idx;
+  float* V = A.v[grp] + N * idx;
+  float p[N], m[N], v[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) { p[j] = P[j]; m[j] = M[j]; v[j] = V[j]; }
+#pragma unroll
+  for (int j = 0; j < N; j++) adam_elem<ADAM>(p[j], m[j], v[j], g[j], A, grp);
+#pragma unroll
+  for (int j = 0; j < N; j++) { P[j] = p[j]; M[j] = m[j]; V[j] = v[j]; }
+}
+
+template <bool STAGE, int ADAM>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int P, int deg, int sh_stride, const float* __restrict__ means3D, const float* __restrict__ dc,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -528,13 +554,18 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     uint32_t cap, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_ddc, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
-    float* __restrict__ dL_dcov3D) {
+    float* __restrict__ dL_dcov3D, const GsrAdamArgs A) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
   __shared__ int32_t need_sh[256];
   const int S = 3 * sh_stride, Sp = S | 1;
   const size_t row0 = (size_t)blockIdx.x * 256;
   const int rows = (int)min((size_t)256, (size_t)P - row0);
   if (STAGE) {
+    // rows to fetch: those with instances (their coefficients enter the gradient); with the optimizer folded in, every
+    // row that will be UPDATED (all of them / the visible ones), since the update reads the parameter from the staged copy
+    if (ADAM == 1) need_sh[threadIdx.x] = (int)threadIdx.x < rows ? 1 : 0;
+    else if (ADAM == 2) need_sh[threadIdx.x] = (int)threadIdx.x < rows ? (radii[row0 + threadIdx.x] > 0 ? 1 : 0) : 0;
+    else
     need_sh[threadIdx.x] = (int)threadIdx.x < rows ? (int32_t)min(tiles_touched[row0 + threadIdx.x], 1u) : 0;
     __syncthreads();
     stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds, need_sh);   // only the rows of Gaussians with instances are read below
@@ -793,11 +824,92 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 
   // ---- write every output (zeros for culled Gaussians: no memset pass needed) ----
   if (active) {
-#pragma unroll
-    for (int j = 0; j < 3; j++) dL_dmeans3D[3 * (size_t)idx + j] = g_mean[j];
     dL_dmeans2D[3 * (size_t)idx + 0] = g_m2d[0];
     dL_dmeans2D[3 * (size_t)idx + 1] = g_m2d[1];
     dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
+  }
+  if (ADAM) {
+    // ---- optimizer step instead of gradient stores (raw-parameter call form: the gradients above ARE the leaves') ----
+    const bool upd = active && (ADAM == 1 || radii[idx] > 0);
+    if (upd) {
+      adam_row<ADAM, 3>(A, 0, (size_t)idx, g_mean);
+      const float bk0 = have_sh ? bs[0] : 0.f;
+      const float g_dc[3] = {bk0 * g_col[0], bk0 * g_col[1], bk0 * g_col[2]};
+      adam_row<ADAM, 3>(A, 1, (size_t)idx, g_dc);
+      adam_row<ADAM, 1>(A, 3, (size_t)idx, &g_opac);
+      adam_row<ADAM, 3>(A, 4, (size_t)idx, g_scale);
+      adam_row<ADAM, 4>(A, 5, (size_t)idx, g_rot);
+    }
+    if (STAGE) {
+      // f_rest: dL/dsh[k][c] = basis_k * dL/drgb_c is rank one, so a row's gradient is 19 numbers (basis values, masked
+      // dL/drgb) kept in LDS next to the staged PARAMETER rows; the update then runs over the block's span of f_rest as flat
+      // 16-B pieces (coalesced m / v / p traffic), forming each element's gradient on the fly.
+      float* fac = sh_lds + 256 * Sp + threadIdx.x * 19;
+#pragma unroll
+      for (int k = 0; k < 16; k++) fac[k] = (have_sh && k < K) ? bs[k] : 0.f;
+      fac[16] = g_col[0]; fac[17] = g_col[1]; fac[18] = g_col[2];
+      __syncthreads();
+      const float* facs = sh_lds + 256 * Sp;
+      const int nflt = rows * S, n4 = nflt >> 2;
+      const int dr = 1024 / S, dcol = 1024 - dr * S;
+      int r = (threadIdx.x * 4) / S, c = threadIdx.x * 4 - r * S;
+      float* Pg = A.p[2] + row0 * S;
+      float* Mg = A.m[2] + row0 * S;
+      float* Vg = A.v[2] + row0 * S;
+      for (int i = threadIdx.x; i < n4; i += 256) {
+        if (ADAM == 2 && need_sh[r] <= 0 && need_sh[min(r + (c + 3 >= S ? 1 : 0), rows - 1)] <= 0) {
+          r += dr; c += dcol;                   // a piece of invisible rows only: neither read nor written
+          if (c >= S) { c -= S; r++; }
+          continue;
+        }
+        const gsr_f4 m4 = gsr_ld_stream(Mg + 4 * (size_t)i), v4 = gsr_ld_stream(Vg + 4 * (size_t)i);
+        float pp[4], mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        int rr = r, cc = c;
+        bool any = false, all = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const bool vis = need_sh[rr] > 0;
+          pp[k] = sh_lds[rr * Sp + cc];                     // (undefined for rows that were not fetched: not stored then)
+          if (vis) {
+            const int kk = cc / 3, ch = cc - 3 * kk;
+            const float g = facs[rr * 19 + kk + 1] * facs[rr * 19 + 16 + ch];
+            adam_elem<ADAM>(pp[k], mm[k], vv[k], g, A, 2);
+            any = true;
+          } else {
+            all = false;
+          }
+          if (++cc == S) { cc = 0; rr++; }
+        }
+        if (all) {
+          gsr_st_stream(Pg + 4 * (size_t)i, gsr_f4{pp[0], pp[1], pp[2], pp[3]});
+          gsr_st_stream(Mg + 4 * (size_t)i, gsr_f4{mm[0], mm[1], mm[2], mm[3]});
+          gsr_st_stream(Vg + 4 * (size_t)i, gsr_f4{vv[0], vv[1], vv[2], vv[3]});
+        } else if (any) {   // a 16-B piece straddling a visible and an invisible row: element stores
+          int r2 = r, c2 = c;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (need_sh[r2] > 0) { Pg[4 * (size_t)i + k] = pp[k]; Mg[4 * (size_t)i + k] = mm[k]; Vg[4 * (size_t)i + k] = vv[k]; }
+            if (++c2 == S) { c2 = 0; r2++; }
+          }
+        }
+        r += dr; c += dcol;
+        if (c >= S) { c -= S; r++; }
+      }
+      for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {   // tail of a span whose length is not a multiple of 4
+        const int r2 = e / S, c2 = e - r2 * S;
+        if (need_sh[r2] > 0) {
+          const int kk = c2 / 3, ch = c2 - 3 * kk;
+          float pv = sh_lds[r2 * Sp + c2], mv = Mg[e], vvv = Vg[e];
+          adam_elem<ADAM>(pv, mv, vvv, facs[r2 * 19 + kk + 1] * facs[r2 * 19 + 16 + ch], A, 2);
+          Pg[e] = pv; Mg[e] = mv; Vg[e] = vvv;
+        }
+      }
+    }
+    return;
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) dL_dmeans3D[3 * (size_t)idx + j] = g_mean[j];
     dL_dopacities[idx] = g_opac;
     if (dL_dcolors) {
 #pragma unroll
@@ -907,12 +1019,27 @@ void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, in
 #undef GSR_PRE_FWD_ARGS
 }
 
-void gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii,
-                               const char* geom, const GsrGeomLayout& L, const float4* igrad, uint32_t cap,
-                               const gsr_grads* gr, hipStream_t st) {
+// adam: nullptr (plain backward) or the folded optimizer step; adam_mode 1 dense / 2 sparse.  Returns 0, or -1 when the
+// folded form does not apply to these inputs (the caller reports the error).
+int gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii,
+                              const char* geom, const GsrGeomLayout& L, const float4* igrad, uint32_t cap,
+                              const gsr_grads* gr, const GsrAdamArgs* adam, int adam_mode, hipStream_t st) {
   const int P = g->P;
   size_t lds = 0;
-  const bool stage = can_stage_sh(s, g, &lds) && gr->dL_dshs && (((uintptr_t)gr->dL_dshs & 15) == 0);
+  GsrAdamArgs A;
+  memset(&A, 0, sizeof(A));
+  bool stage;
+  if (adam) {
+    // raw-parameter call form with dc / rest passed separately: every gradient of this kernel is a leaf's gradient
+    if (!g->raw_activations || !g->dc || g->colors_precomp || g->cov3D_precomp || !g->scales || !g->rotations) return -1;
+    stage = g->shs != nullptr;
+    if (stage && !can_stage_sh(s, g, &lds)) return -1;     // (f_rest rows are updated from their staged copy)
+    if (!stage && g->sh_coeffs != 0) return -1;
+    if (stage) lds += (size_t)256 * 19 * sizeof(float);
+    A = *adam;
+  } else {
+    stage = can_stage_sh(s, g, &lds) && gr->dL_dshs && (((uintptr_t)gr->dL_dshs & 15) == 0);
+  }
 #define GSR_PRE_BWD_ARGS                                                                                              \
   P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations, \
       g->cov3D_precomp, s->scale_modifier, s->viewmatrix, s->projmatrix, s->campos, s->image_width, s->image_height,  \
@@ -920,12 +1047,25 @@ void gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, co
       (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), igrad,                       \
       (const uint32_t*)(geom + L.meta) + 2, cap, gr->dL_dmeans3D,                                                      \
       gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities, gr->dL_dscales, gr->dL_drotations, \
-      gr->dL_dcov3D
-  if (stage)
-    GSR_LAUNCH("preprocess_bwd", k_preprocess_bwd<true>, dim3((P + 255) / 256), dim3(256), lds, st, GSR_PRE_BWD_ARGS);
-  else
-    GSR_LAUNCH("preprocess_bwd", k_preprocess_bwd<false>, dim3((P + 255) / 256), dim3(256), 0, st, GSR_PRE_BWD_ARGS);
+      gr->dL_dcov3D, A
+#define GSR_PRE_BWD(ST, AD)                                                                                            \
+  do {                                                                                                                 \
+    if (lds > 48 * 1024)                                                                                               \
+      (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<ST, AD>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                (int)lds);                                                                             \
+    GSR_LAUNCH(AD ? "preprocess_bwd_adam" : "preprocess_bwd", (k_preprocess_bwd<ST, AD>), dim3((P + 255) / 256),       \
+               dim3(256), ST ? lds : 0, st, GSR_PRE_BWD_ARGS);                                                         \
+  } while (0)
+  if (!adam) {
+    if (stage) GSR_PRE_BWD(true, 0); else GSR_PRE_BWD(false, 0);
+  } else if (adam_mode == 2) {
+    if (stage) GSR_PRE_BWD(true, 2); else GSR_PRE_BWD(false, 2);
+  } else {
+    if (stage) GSR_PRE_BWD(true, 1); else GSR_PRE_BWD(false, 1);
+  }
+#undef GSR_PRE_BWD
 #undef GSR_PRE_BWD_ARGS
+  return 0;
 }
 
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,

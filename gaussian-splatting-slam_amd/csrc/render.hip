@@ -17,6 +17,9 @@
 // Record = (sum g dx, sum g dy, sum g dx^2, sum g dx dy) (sum g dy^2, dL/dopacity_eff, d_r, d_g) (d_b, d_invdepth, -, -)
 // with g = dL/dpower and d = mean - pixel: raw moments; k_preprocess_bwd turns their per-Gaussian totals into
 // dL/dmean2D and dL/dconic.
+#include <stdlib.h>
+#include <string.h>
+
 #include "gsr_common.h"
 
 #define ALPHA_MIN (1.0f / 255.0f)
@@ -413,6 +416,172 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, second form: ONE wave per tile, four pixels per lane.
+//
+// The micro-benchmark (profiles/r02_valu_microbench.txt) prices the cross-lane instructions of the reduction at 1.6x
+// (DPP add) and 3.2x (v_permlane32/16_swap) a plain VALU instruction, which makes the nine-value wave reduction ~45 % of
+// a hit's issue cost in the four-waves-per-tile kernel above - and it is paid per (8x8 quadrant, Gaussian).  Here a lane owns
+// the same (x, y) of all four 8x8 sub-blocks of the tile, accumulates the nine sums of a Gaussian over its sub-blocks in
+// registers (plain fma) and the wave reduces ONCE per (tile, Gaussian): the reduction is shared by up to four hits, the
+// wave's total IS the tile's total (no per-wave slabs, no cross-wave pass, no workgroup barrier, 6 KB of LDS instead of
+// 31 KB), and a sub-block the Gaussian misses still costs only the 9-instruction reject test behind a scalar skip.
+// Summation order is fixed (sub-blocks 0..3 in a lane, then the halving tree): bitwise reproducible like the first form.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef BWD1_BATCH
+#define BWD1_BATCH 64
+#endif
+template <bool DEPTH>
+__global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x, const uint2* __restrict__ ranges,
+                                                        const uint32_t* __restrict__ point_list,
+                                                        const float4* __restrict__ rec, const float* __restrict__ bg,
+                                                        const float* __restrict__ final_T,
+                                                        const uint32_t* __restrict__ n_contrib,
+                                                        const float* __restrict__ dL_dpix,
+                                                        const float* __restrict__ dL_dinvdepth,
+                                                        const uint32_t* __restrict__ slot_of_pos,
+                                                        float4* __restrict__ igrad) {
+  __shared__ float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH];   // +2: the prefetch may touch [n+1]
+  __shared__ float4 outb[BWD1_BATCH * GSR_IGRAD_F4];                          // the batch's gradient records
+  const int tile = blockIdx.x;
+  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+  const int lane = threadIdx.x;
+  const uint2 range = ranges[tile];
+  const int len = (int)(range.y - range.x);
+  if (len == 0) return;
+
+  const size_t N = (size_t)W * H;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  // sub-block s: origin (8 (s & 1), 8 (s >> 1)) inside the tile
+  const float px0 = (float)(tile_x * GSR_TILE + (lane & 7)), py0 = (float)(tile_y * GSR_TILE + (lane >> 3));
+  float T[4], S[4], gp0[4], gp1[4], gp2[4], gd[4], nTb[4];
+  int last[4];
+  int sub_last[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int px = tile_x * GSR_TILE + (s & 1) * 8 + (lane & 7), py = tile_y * GSR_TILE + (s >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const size_t pix = (size_t)py * W + px;
+    T[s] = inside ? final_T[pix] : 0.f;
+    last[s] = inside ? (int)n_contrib[pix] : 0;
+    gp0[s] = inside ? dL_dpix[pix] : 0.f;
+    gp1[s] = inside ? dL_dpix[N + pix] : 0.f;
+    gp2[s] = inside ? dL_dpix[2 * N + pix] : 0.f;
+    gd[s] = (DEPTH && inside) ? dL_dinvdepth[pix] : 0.f;
+    nTb[s] = -T[s] * (bg0 * gp0[s] + bg1 * gp1[s] + bg2 * gp2[s]);
+    S[s] = 0.f;
+    int m = last[s];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    sub_last[s] = __builtin_amdgcn_readfirstlane(m);   // deepest contributor among this sub-block's 64 pixels
+  }
+  const int toDo = min(len, max(max(sub_last[0], sub_last[1]), max(sub_last[2], sub_last[3])));
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // entries beyond the deepest contributor of any pixel are never visited: their records are zeros
+  for (int i = toDo + lane; i < len; i += 64) {
+    float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + i];
+    dst[0] = z4; dst[1] = z4; dst[2] = z4;
+  }
+  int vzero;   // keeps the LDS base in a VGPR (see k_render_bwd)
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  const float4 *s0v = s0 + vzero, *s1v = s1 + vzero, *s2v = s2 + vzero;
+  const bool lane_bit3 = (lane & 8) != 0, octet_lead = (lane & 7) == 0;
+  const bool u1_lead = DEPTH ? (lane & 31) == 0 : lane == 63;
+  const int u1_slot = DEPTH ? 8 + (lane >> 5) : 8;
+  const int octet_val = (((lane >> 3) & 1) << 2) | ((lane >> 3) & 2) | (((lane >> 3) & 4) >> 2);
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f, acc5 = 0.f, acc6 = 0.f, acc7 = 0.f, acc8 = 0.f,
+        acc9 = 0.f;
+
+  const int rounds = (toDo + BWD1_BATCH - 1) / BWD1_BATCH;
+  for (int b = 0; b < rounds; b++) {
+    __syncthreads();   // (one wave: orders this wave's LDS reads of the previous batch before the stores below)
+    const int e_idx = toDo - 1 - (b * BWD1_BATCH + lane);   // back-to-front staging
+    if (e_idx >= 0) {
+      const uint32_t id32 = point_list[range.x + e_idx];
+      if (id32 != 0xFFFFFFFFu) {
+        const size_t id = id32;
+        s0[lane] = rec[3 * id + 0];
+        s1[lane] = rec[3 * id + 1];
+        s2[lane] = rec[3 * id + 2];
+      } else {
+        s0[lane] = z4;
+        s1[lane] = make_float4(0.f, 0.f, 3.0e38f, 0.f);
+        s2[lane] = z4;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (BWD1_BATCH * GSR_IGRAD_F4) / 64; i++) outb[i * 64 + lane] = z4;
+    __syncthreads();
+    const int n = min(BWD1_BATCH, toDo - b * BWD1_BATCH);
+    float4 a = s0v[0], bb = s1v[0];
+    for (int j = 0; j < n; j++) {
+      const float4 an = s0v[j + 1], bn = s1v[j + 1];   // next entry's record, in flight while this one is processed
+      const int entry1 = toDo - (b * BWD1_BATCH + j);  // 1-based list position of this entry
+      bool any = false;                                // (wave-uniform)
+      const float dx0 = a.x - px0, dy0 = a.y - py0;
+      float4 c;
+      bool have_c = false;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        if (entry1 > sub_last[s]) continue;            // scalar: every pixel of this sub-block finished earlier
+        const float dx = dx0 - (float)((s & 1) * 8), dy = dy0 - (float)((s >> 1) * 8);
+        const float power = gsr_power2(a, bb, dx, dy);
+        const bool pre = entry1 <= last[s] && power >= bb.z;
+        const uint64_t m_pre = BALLOT(entry1 <= last[s]) & BALLOT(power >= bb.z);
+        if (m_pre == 0ull) continue;
+        const float G = __builtin_amdgcn_exp2f(power);
+        const float alpha = fminf(0.99f, bb.y * G);
+        const bool ok = pre && power <= 0.0f && alpha >= ALPHA_MIN;
+        if ((m_pre & BALLOT(power <= 0.0f) & BALLOT(alpha >= ALPHA_MIN)) == 0ull) continue;
+        if (!have_c) { c = s2v[j]; have_c = true; }
+        any = true;
+        const float a_e = ok ? alpha : 0.f;
+        const float G_e = ok ? G : 0.f;
+        const float rcp = __builtin_amdgcn_rcpf(1.0f - a_e);
+        T[s] = T[s] * rcp;
+        const float dch = a_e * T[s];
+        float cg = bb.w * gp0[s] + c.x * gp1[s] + c.y * gp2[s];
+        if (DEPTH) cg += c.z * gd[s];
+        const float diff = cg - S[s];
+        S[s] = __builtin_fmaf(a_e, diff, S[s]);
+        const float dL_dalpha = diff * T[s] + nTb[s] * rcp;
+        const float v5 = G_e * dL_dalpha;
+        const float g = bb.y * v5;
+        const float t0 = g * dx, t1 = g * dy;
+        acc0 += t0;
+        acc1 += t1;
+        acc2 = __builtin_fmaf(t0, dx, acc2);
+        acc3 = __builtin_fmaf(t0, dy, acc3);
+        acc4 = __builtin_fmaf(t1, dy, acc4);
+        acc5 += v5;
+        acc6 = __builtin_fmaf(dch, gp0[s], acc6);
+        acc7 = __builtin_fmaf(dch, gp1[s], acc7);
+        acc8 = __builtin_fmaf(dch, gp2[s], acc8);
+        if (DEPTH) acc9 = __builtin_fmaf(dch, gd[s], acc9);
+      }
+      if (any) {
+        float u0, u1;
+        if (DEPTH) wave_sum10_halving(acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7, acc8, acc9, lane_bit3, u0, u1);
+        else wave_sum9_halving(acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7, acc8, lane_bit3, u0, u1);
+        float* dst = reinterpret_cast<float*>(outb) + 12 * j;
+        if (octet_lead) dst[octet_val] = u0;
+        if (u1_lead) dst[u1_slot] = u1;
+        acc0 = acc1 = acc2 = acc3 = acc4 = acc5 = acc6 = acc7 = acc8 = 0.f;
+        if (DEPTH) acc9 = 0.f;
+      }
+      a = an;
+      bb = bn;
+    }
+    __syncthreads();
+    // flush the batch: 3 float4 per entry, at the entry's emission slot (grouped per Gaussian for k_preprocess_bwd)
+    for (int q = lane; q < n * GSR_IGRAD_F4; q += 64) {
+      const int j = q / GSR_IGRAD_F4, part = q - j * GSR_IGRAD_F4;
+      const int e = toDo - 1 - (b * BWD1_BATCH + j);
+      igrad[(size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + e] + part] = outb[q];
+    }
+  }
+}
+
 void gsr_launch_render_fwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,
                            const uint32_t* point_list, const float4* rec, float* out_color, float* out_invdepth,
                            float* final_T, uint32_t* n_contrib, hipStream_t st) {
@@ -430,6 +599,19 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
                            const uint32_t* point_list, const float4* rec, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dinvdepth,
                            const uint32_t* slot_of_pos, float4* igrad, hipStream_t st) {
+  // One wave per tile needs enough tiles to keep 1024 SIMDs busy: below ~2 tiles per SIMD the four-waves-per-tile form
+  // (same results up to summation order inside a tile) has the shorter critical path.  GSR_BWD_FORM=quad|tile forces one.
+  static const char* form = getenv("GSR_BWD_FORM");
+  const bool quad = form ? !strcmp(form, "quad") : tiles < 2048;
+  if (!quad || (form && !strcmp(form, "tile"))) {
+    if (dL_dinvdepth)
+      GSR_LAUNCH("render_bwd", k_render_bwd_tile<true>, dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height,
+                 grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
+    else
+      GSR_LAUNCH("render_bwd", k_render_bwd_tile<false>, dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height,
+                 grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
+    return;
+  }
   if (dL_dinvdepth)
     GSR_LAUNCH("render_bwd", k_render_bwd<true>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height,
                grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);

@@ -45,6 +45,13 @@ class gsr_grads(C.Structure):
     ]
 
 
+class gsr_fused_adam(C.Structure):
+    _fields_ = [
+        ("exp_avg", C.c_void_p * 6), ("exp_avg_sq", C.c_void_p * 6), ("lr", C.c_float * 6), ("step", C.c_int64 * 6),
+        ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("sparse", C.c_int32),
+    ]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "gsr_abi_version": (C.c_int, []),
@@ -70,6 +77,9 @@ EXPORTS = {
     "gsr_backward": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.POINTER(gsr_grads), C.c_void_p]),
+    "gsr_backward_adam": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.POINTER(gsr_grads), C.POINTER(gsr_fused_adam), C.c_void_p]),
     "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_geometry_views": (C.c_int, [C.c_void_p, C.c_int32] + [C.POINTER(C.c_void_p)] * 6),
     "gsr_debug_wave_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -50,6 +50,65 @@ def defer_sh_until(event):
     _sh_ready_event = event
 
 
+# One-shot hand-off from the trainer: fold THIS optimizer's step into the next rasterizer backward (gsr_backward_adam).
+_fused_optimizer = None
+fused_backward_count = 0
+
+
+def fuse_optimizer_into_next_backward(optimizer):
+    """`optimizer`: a FusedAdam / SparseGaussianAdam over the model's six parameter groups (named xyz, f_dc, f_rest, opacity,
+    scaling, rotation as in reference scene/gaussian_model.py:160-168), or None to cancel.  The next backward of a rasterizer
+    call that received exactly those parameters (raw-parameter call form, dc / rest separate) then applies the Adam update
+    itself and returns no gradient for them; any other backward leaves the hand-off in place, so the caller can check
+    `fuse_pending()` afterwards and fall back to optimizer.step()."""
+    global _fused_optimizer
+    _fused_optimizer = optimizer
+
+
+def fuse_pending():
+    return _fused_optimizer is not None
+
+
+_GROUP_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+
+def _fused_adam_struct(opt, tensors):
+    """gsr_fused_adam for optimizer `opt` if its six groups are exactly `tensors` (means3D, dc, sh, opacities, scales,
+    rotations as saved by the forward), else None."""
+    groups = {g.get("name"): g for g in opt.param_groups}
+    if any(n not in groups for n in _GROUP_ORDER):
+        return None
+    ps = []
+    for n, t in zip(_GROUP_ORDER, tensors):
+        p = groups[n]["params"][0]
+        if t is None:
+            if p.numel() != 0:
+                return None
+        elif p.data_ptr() != t.data_ptr() or p.numel() != t.numel() or not p.is_contiguous() or p.dtype != torch.float32:
+            return None
+        ps.append(p)
+    fa = _C.gsr_fused_adam()
+    sparse = isinstance(opt, SparseGaussianAdam)
+    keep = []
+    for i, (n, p) in enumerate(zip(_GROUP_ORDER, ps)):
+        st = opt.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if not sparse:
+            st["step"] += 1
+        fa.exp_avg[i] = st["exp_avg"].data_ptr() if p.numel() else None
+        fa.exp_avg_sq[i] = st["exp_avg_sq"].data_ptr() if p.numel() else None
+        fa.lr[i] = float(groups[n]["lr"])
+        fa.step[i] = int(st["step"]) if not sparse else 1
+        keep.append(st)
+    g0 = opt.param_groups[0]
+    b1, b2 = (0.9, 0.999) if sparse else g0["betas"]
+    fa.beta1, fa.beta2, fa.eps, fa.sparse = float(b1), float(b2), float(g0["eps"]), 1 if sparse else 0
+    return fa, keep
+
+
 def call_stats(device=None, wait=True):
     """Statistics of this device's rasterizer calls: `num_rendered` of the most recent frame whose count has arrived,
     `overflow_frames`, `async_frames`, `sync_frames`.  wait=True first waits for the counts still in flight."""
@@ -240,7 +299,21 @@ class _RasterizeGaussians(torch.autograd.Function):
                 scratch = ws.ensure_scratch(lib, P, R)
                 gr = _C.gsr_grads(*[None if t is None else t.data_ptr() for t in
                                     (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov)])
+                global _fused_optimizer, fused_backward_count
+                fused = None
+                if _fused_optimizer is not None and ctx.raw_activations and dc is not None and colors_precomp is None:
+                    fused = _fused_adam_struct(_fused_optimizer, (means3D, dc, sh, opacities, scales, rotations))
                 try:
+                    if fused is not None:
+                        # the optimizer step rides in the backward's last kernel: no gradient leaves the device registers
+                        _fused_optimizer = None
+                        fused_backward_count += 1
+                        _C.check(lib.gsr_backward_adam(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom),
+                                                       _C.ptr(binning), _C.ptr(img), R, _C.ptr(grad_color),
+                                                       _C.ptr(grad_invdepth), _C.ptr(scratch), scratch.numel(), C.byref(gr),
+                                                       C.byref(fused[0]), _stream()))
+                        ws.stream = cur
+                        return (None, d_means2D, None, None, None, None, None, None, None, None, None, None)
                     _C.check(lib.gsr_backward(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom), _C.ptr(binning),
                                               _C.ptr(img), R, _C.ptr(grad_color), _C.ptr(grad_invdepth),
                                               _C.ptr(scratch), scratch.numel(), C.byref(gr), _stream()))

@@ -19,6 +19,11 @@ class Trainer:
         self.render_fn, self.pipe, self.bg = render_fn, pipe, bg
         self.lambda_dssim = lambda_dssim
         self.world, self.rank = world, rank
+        # "hip_fused" / "hip_sparse_fused": the same two optimizers with their step folded into the rasterizer's backward
+        # (gsr_backward_adam) whenever nothing sits between backward and step: one rank, one view per step, no densification
+        # due.  Same arithmetic, bit for bit; the 59 floats per Gaussian of gradients never leave the kernel.
+        self.fuse_step = optimizer in ("hip_fused", "hip_sparse_fused")
+        optimizer = {"hip_fused": "hip", "hip_sparse_fused": "hip_sparse"}.get(optimizer, optimizer)
         self.optimizer_kind = optimizer
         # like the reference, the model owns the optimizer and the densification statistics (gaussian_model.py:155-176)
         self.optimizer = model.training_setup(optimizer=optimizer)
@@ -73,7 +78,14 @@ class Trainer:
                 loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[v]).mean()
             if len(views) > 1:
                 loss = loss / len(views)
+            fold = self.fuse_step and self.world == 1 and len(views) == 1 and not self._densify_due(self.iteration + 1) \
+                and self.separate_sh
+            if fold:
+                import diff_gaussian_rasterization as dgr
+                dgr.fuse_optimizer_into_next_backward(self.optimizer)
             loss.backward()                                                                      # .grad accumulates
+            if fold and dgr.fuse_pending():
+                dgr.fuse_optimizer_into_next_backward(None)     # the rasterizer could not take it: plain step below
             with torch.no_grad():
                 # densification statistics are per-view: norm BEFORE any cross-rank reduction
                 self.model.add_densification_stats(vsp, vis, radii)                          # train.py:159-160
@@ -108,8 +120,8 @@ class Trainer:
             self.optimizer.zero_grad(set_to_none=True)
         return self.last
 
-    def _densify_due(self):
-        d, it = self.densify, self.iteration
+    def _densify_due(self, it=None):
+        d, it = self.densify, (self.iteration if it is None else it)
         if d is None or it >= d["until_iter"]:
             return False
         return (it > d["from_iter"] and it % d["interval"] == 0) or it % d["reset"] == 0

@@ -163,6 +163,33 @@ int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* r
                  int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth,
                  void* scratch, size_t scratch_bytes, const gsr_grads* grads, void* stream);
 
+/* gsr_backward with the optimizer step folded in (single-GPU training step: reference train.py:139 loss.backward() followed
+ * by :170-179 optimizer.step(), when nothing sits between the two - no gradient exchange, no accumulation over views, no
+ * densification at this iteration).  The six parameter groups of reference scene/gaussian_model.py:160-168 are updated IN PLACE
+ * by the backward's last kernel from the gradients it holds in registers / LDS; those gradients (59 floats per Gaussian at SH
+ * degree 3) are never written to memory, and no separate optimizer kernel re-reads them.
+ *   Requirements: raw_activations = 1 (opacities / scales / rotations are the model's raw parameters), `dc` and `shs` passed
+ *   separately (the separate_sh call form), no colors_precomp / cov3D_precomp.  The arrays of `g` are the parameters themselves
+ *   and are written to (the `const` of gsr_gaussians does not hold for this call).
+ *   Group order of the arrays below: 0 xyz (g->means3D), 1 f_dc (g->dc), 2 f_rest (g->shs), 3 opacity, 4 scaling, 5 rotation.
+ *   sparse = 0: torch.optim.Adam semantics (bias correction; `step` = 1-based step number AFTER this update), every row.
+ *   sparse = 1: SparseGaussianAdam.step(radii > 0, P) semantics (reference train.py:173-176): rows with radii == 0 untouched,
+ *               no bias correction.
+ * grads->dL_dmeans2D is still written (densification statistics, scene/gaussian_model.py:431-433); the other members of `grads`
+ * are ignored.  Same arithmetic as gsr_backward followed by gsr_adam_step / gsr_sparse_adam_step, bit for bit. */
+typedef struct gsr_fused_adam {
+  float* exp_avg[6];
+  float* exp_avg_sq[6];
+  float lr[6];
+  int64_t step[6];
+  double beta1, beta2, eps;
+  int32_t sparse;
+} gsr_fused_adam;
+int gsr_backward_adam(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,
+                      const void* binning_state, const void* image_state, int64_t num_rendered, const float* dL_dcolor,
+                      const float* dL_dinvdepth, void* scratch, size_t scratch_bytes, const gsr_grads* grads,
+                      const gsr_fused_adam* opt, void* stream);
+
 /* GaussianRasterizer.markVisible (near-plane test).  present[P] uint8. */
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream);
 

@@ -121,3 +121,41 @@ def test_fused_l1_ssim_loss_matches_reference_loss(shape, lam):
     v2 = fused_l1_ssim_loss(a2, b.float().cuda(), lam)
     (3.0 * v2).backward()
     assert v2.item() == val.item() and torch.equal(a2.grad, a_gpu.grad)
+
+
+@pytest.mark.parametrize("kind", ["hip", "hip_sparse"])
+def test_optimizer_step_folded_into_backward_is_bit_identical(kind):
+    """gsr_backward_adam (the Adam / SparseGaussianAdam update applied by the rasterizer backward's last kernel, gradients
+    never stored) against backward + the one-launch optimizer kernel: parameters and both moments equal bit for bit after
+    several training steps, densification statistics (means2D gradient) included."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import make_gaussians, fibonacci_cameras, GaussianModel, Trainer
+    cams = fibonacci_cameras(3, 176, 112, seed=91, device="cuda")
+    bg = torch.tensor([0.1, 0.2, 0.05], device="cuda")
+    pipe = PipelineParams()
+    teacher = GaussianModel.from_raw(make_gaussians(3000, 3, seed=92, scale_factor=0.7).to("cuda"), requires_grad=False)
+    with torch.no_grad():
+        gts = {i: render(c, teacher, pipe, bg)["render"].clone() for i, c in enumerate(cams)}
+    runs = {}
+    for fused in (False, True):
+        model = GaussianModel.from_raw(make_gaussians(3000, 3, seed=93, scale_factor=0.7).to("cuda"))
+        tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True, optimizer=kind + ("_fused" if fused else ""))
+        n0 = dgr.fused_backward_count
+        for it in range(7):
+            tr.step(it % 3)
+        tr.finish()
+        torch.cuda.synchronize()
+        assert dgr.fused_backward_count - n0 == (7 if fused else 0)
+        st = {}
+        for name, p in zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), model.parameters()):
+            s = tr.optimizer.state[p]
+            st[name] = (p.detach().clone(), s["exp_avg"].clone(), s["exp_avg_sq"].clone())
+        runs[fused] = (st, model.xyz_gradient_accum.clone(), model.denom.clone())
+    for name in runs[False][0]:
+        for a, b, what in zip(runs[False][0][name], runs[True][0][name], ("param", "exp_avg", "exp_avg_sq")):
+            assert torch.equal(a, b), (name, what, float((a - b).abs().max()))
+    assert torch.equal(runs[False][1], runs[True][1]) and torch.equal(runs[False][2], runs[True][2])
+    # and the parameters did move
+    ref = GaussianModel.from_raw(make_gaussians(3000, 3, seed=93, scale_factor=0.7).to("cuda"))
+    assert not torch.equal(ref._features_rest, runs[True][0]["f_rest"][0])
