@@ -16,6 +16,7 @@
 void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool,
                                hipStream_t);
 void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, hipStream_t);
+void gsr_launch_adam_culled_rows(int, int, const char*, const GsrGeomLayout&, const GsrAdamArgs&, hipStream_t);
 int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
                               const GsrGeomLayout&, const float4*, uint32_t, const gsr_grads*, const GsrAdamArgs*, int,
                               hipStream_t);
@@ -394,6 +395,28 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
                              out_invdepth, for_backward != 0, false, nullptr, stream);
 }
 
+static int adam_args(const gsr_gaussians* g, const gsr_fused_adam* opt, GsrAdamArgs& A) {
+  float* params[6] = {(float*)g->means3D, (float*)g->dc, (float*)g->shs, (float*)g->opacities, (float*)g->scales,
+                      (float*)g->rotations};
+  for (int i = 0; i < 6; i++) {
+    const bool present = params[i] != nullptr;
+    if (present && (!opt->exp_avg[i] || !opt->exp_avg_sq[i])) {
+      gsr_set_error("fused adam: no moments for parameter group %d", i);
+      return GSR_ERR_INVALID_ARGUMENT;
+    }
+    A.p[i] = params[i]; A.m[i] = opt->exp_avg[i]; A.v[i] = opt->exp_avg_sq[i];
+    A.lr[i] = opt->lr[i];
+    const double bc1 = 1.0 - pow(opt->beta1, (double)opt->step[i]);
+    const double bc2 = 1.0 - pow(opt->beta2, (double)opt->step[i]);
+    A.step_size[i] = opt->sparse == 1 ? 0.f : (float)((double)opt->lr[i] / bc1);
+    A.inv_bc2_sqrt[i] = opt->sparse == 1 ? 0.f : (float)(1.0 / sqrt(bc2));
+  }
+  A.beta1 = (float)opt->beta1; A.beta2 = (float)opt->beta2;
+  A.omb1 = (float)(1.0 - opt->beta1); A.omb2 = (float)(1.0 - opt->beta2);
+  A.eps = (float)opt->eps;
+  return 0;
+}
+
 static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,
                          const void* binning_state, const void* image_state, int64_t num_rendered, const float* dL_dcolor,
                          const float* dL_dinvdepth, void* scratch, size_t scratch_bytes, const gsr_grads* grads,
@@ -429,28 +452,10 @@ static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const in
     if ((rc = debug_sync(s, st, "render backward"))) return rc;
   }
   GsrAdamArgs A;
-  if (opt) {
-    float* params[6] = {(float*)g->means3D, (float*)g->dc, (float*)g->shs, (float*)g->opacities, (float*)g->scales,
-                        (float*)g->rotations};
-    for (int i = 0; i < 6; i++) {
-      const bool present = params[i] != nullptr;
-      if (present && (!opt->exp_avg[i] || !opt->exp_avg_sq[i])) {
-        gsr_set_error("backward_adam: no moments for parameter group %d", i);
-        return GSR_ERR_INVALID_ARGUMENT;
-      }
-      A.p[i] = params[i]; A.m[i] = opt->exp_avg[i]; A.v[i] = opt->exp_avg_sq[i];
-      A.lr[i] = opt->lr[i];
-      const double bc1 = 1.0 - pow(opt->beta1, (double)opt->step[i]);
-      const double bc2 = 1.0 - pow(opt->beta2, (double)opt->step[i]);
-      A.step_size[i] = opt->sparse ? 0.f : (float)((double)opt->lr[i] / bc1);
-      A.inv_bc2_sqrt[i] = opt->sparse ? 0.f : (float)(1.0 / sqrt(bc2));
-    }
-    A.beta1 = (float)opt->beta1; A.beta2 = (float)opt->beta2;
-    A.omb1 = (float)(1.0 - opt->beta1); A.omb2 = (float)(1.0 - opt->beta2);
-    A.eps = (float)opt->eps;
-  }
-  if (gsr_launch_preprocess_bwd(s, g, radii, geom, GL, igrad, (uint32_t)R, grads, opt ? &A : nullptr,
-                                opt && opt->sparse ? 2 : 1, st)) {
+  if (opt && (rc = adam_args(g, opt, A))) return rc;
+  // rows: 0 every row (dense) / 1 rows with radii > 0, no bias correction (sparse) / 2 dense, rows with instances only
+  const int mode = !opt ? 0 : (opt->sparse == 1 ? 2 : (opt->sparse == 2 ? 3 : 1));
+  if (gsr_launch_preprocess_bwd(s, g, radii, geom, GL, igrad, (uint32_t)R, grads, opt ? &A : nullptr, mode, st)) {
     gsr_set_error("backward_adam needs the raw-parameter call form with dc / shs passed separately (raw_activations = 1, "
                   "dc != NULL, no colors_precomp / cov3D_precomp, every stored SH coefficient active)");
     return GSR_ERR_INVALID_ARGUMENT;
@@ -474,6 +479,25 @@ int gsr_backward_adam(const gsr_settings* s, const gsr_gaussians* g, const int32
   if (!opt) { gsr_set_error("backward_adam: null optimizer arguments"); return GSR_ERR_INVALID_ARGUMENT; }
   return backward_impl(s, g, radii, geometry_state, binning_state, image_state, num_rendered, dL_dcolor, dL_dinvdepth,
                        scratch, scratch_bytes, grads, opt, stream);
+}
+
+int gsr_adam_step_culled_rows(const gsr_gaussians* g, const void* geometry_state, const gsr_fused_adam* opt, void* stream) {
+  if (!g || !geometry_state || !opt || opt->sparse == 1) {
+    gsr_set_error("adam_step_culled_rows: bad arguments (dense Adam only)");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (g->P == 0) return 0;
+  if (!g->raw_activations || !g->dc || g->colors_precomp || g->cov3D_precomp || !g->scales || !g->rotations ||
+      (g->shs == nullptr) != (g->sh_coeffs == 0)) {
+    gsr_set_error("adam_step_culled_rows needs the raw-parameter call form with dc / shs passed separately");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  GsrAdamArgs A;
+  int rc = adam_args(g, opt, A);
+  if (rc) return rc;
+  gsr_launch_adam_culled_rows(g->P, g->shs ? g->sh_coeffs : 0, (const char*)geometry_state, gsr_geom_layout(g->P), A,
+                              (hipStream_t)stream);
+  return gsr_check(hipGetLastError(), "adam culled rows launch");
 }
 
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream) {

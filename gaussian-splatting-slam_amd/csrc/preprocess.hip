@@ -537,7 +537,7 @@ __device__ __forceinline__ void adam_row(const GsrAdamArgs& A, const int grp, co
 #pragma unroll
   for (int j = 0; j < N; j++) { p[j] = P[j]; m[j] = M[j]; v[j] = V[j]; }
 #pragma unroll
-  for (int j = 0; j < N; j++) adam_elem<ADAM>(p[j], m[j], v[j], g[j], A, grp);
+  for (int j = 0; j < N; j++) adam_elem<ADAM == 2 ? 2 : 1>(p[j], m[j], v[j], g[j], A, grp);
 #pragma unroll
   for (int j = 0; j < N; j++) { P[j] = p[j]; M[j] = m[j]; V[j] = v[j]; }
 }
@@ -563,6 +563,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   if (STAGE) {
     // rows to fetch: those with instances (their coefficients enter the gradient); with the optimizer folded in, every
     // row that will be UPDATED (all of them / the visible ones), since the update reads the parameter from the staged copy
+    // (ADAM = 3: dense Adam on the rows WITH instances only; the others got their zero-gradient update from k_adam_culled_rows)
     if (ADAM == 1) need_sh[threadIdx.x] = (int)threadIdx.x < rows ? 1 : 0;
     else if (ADAM == 2) need_sh[threadIdx.x] = (int)threadIdx.x < rows ? (radii[row0 + threadIdx.x] > 0 ? 1 : 0) : 0;
     else
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   }
   if (ADAM) {
     // ---- optimizer step instead of gradient stores (raw-parameter call form: the gradients above ARE the leaves') ----
-    const bool upd = active && (ADAM == 1 || radii[idx] > 0);
+    const bool upd = active && (ADAM == 1 || (ADAM == 2 ? radii[idx] > 0 : visible));
     if (upd) {
       adam_row<ADAM, 3>(A, 0, (size_t)idx, g_mean);
       const float bk0 = have_sh ? bs[0] : 0.f;
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       float* Mg = A.m[2] + row0 * S;
       float* Vg = A.v[2] + row0 * S;
       for (int i = threadIdx.x; i < n4; i += 256) {
-        if (ADAM == 2 && need_sh[r] <= 0 && need_sh[min(r + (c + 3 >= S ? 1 : 0), rows - 1)] <= 0) {
+        if (ADAM != 1 && need_sh[r] <= 0 && need_sh[min(r + (c + 3 >= S ? 1 : 0), rows - 1)] <= 0) {
           r += dr; c += dcol;                   // a piece of invisible rows only: neither read nor written
           if (c >= S) { c -= S; r++; }
           continue;
@@ -868,12 +869,15 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         bool any = false, all = true;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const bool vis = need_sh[rr] > 0;
+          // ADAM = 3 owns every 16-B piece that touches a row with instances, WHOLE: the elements of a neighbouring row
+          // without instances in it get their (zero-gradient) dense update here too - their `fac` entries are zeros and the
+          // staging fetched the straddling piece - so no piece is ever split between this kernel and k_adam_culled_rows
+          const bool vis = ADAM == 3 ? true : need_sh[rr] > 0;
           pp[k] = sh_lds[rr * Sp + cc];                     // (undefined for rows that were not fetched: not stored then)
           if (vis) {
             const int kk = cc / 3, ch = cc - 3 * kk;
             const float g = facs[rr * 19 + kk + 1] * facs[rr * 19 + 16 + ch];
-            adam_elem<ADAM>(pp[k], mm[k], vv[k], g, A, 2);
+            adam_elem<ADAM == 2 ? 2 : 1>(pp[k], mm[k], vv[k], g, A, 2);
             any = true;
           } else {
             all = false;
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
           gsr_st_stream(Pg + 4 * (size_t)i, gsr_f4{pp[0], pp[1], pp[2], pp[3]});
           gsr_st_stream(Mg + 4 * (size_t)i, gsr_f4{mm[0], mm[1], mm[2], mm[3]});
           gsr_st_stream(Vg + 4 * (size_t)i, gsr_f4{vv[0], vv[1], vv[2], vv[3]});
-        } else if (any) {   // a 16-B piece straddling a visible and an invisible row: element stores
+        } else if (any) {   // (sparse only) a piece straddling a visible and an invisible row: element stores
           int r2 = r, c2 = c;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
@@ -900,7 +904,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         if (need_sh[r2] > 0) {
           const int kk = c2 / 3, ch = c2 - 3 * kk;
           float pv = sh_lds[r2 * Sp + c2], mv = Mg[e], vvv = Vg[e];
-          adam_elem<ADAM>(pv, mv, vvv, facs[r2 * 19 + kk + 1] * facs[r2 * 19 + 16 + ch], A, 2);
+          adam_elem<ADAM == 2 ? 2 : 1>(pv, mv, vvv, facs[r2 * 19 + kk + 1] * facs[r2 * 19 + 16 + ch], A, 2);
           Pg[e] = pv; Mg[e] = mv; Vg[e] = vvv;
         }
       }
@@ -958,6 +962,68 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       }
     }
   }
+}
+
+// Dense Adam on the rows that reached no tile in this forward (their gradient is exactly zero): m, v decay and the parameter
+// follows its momentum, as torch.optim.Adam does for a zero gradient.  Needs only `tiles_touched` of the forward, so it can run on
+// another stream WHILE the compositing kernels (VALU-bound, little HBM traffic) run; k_preprocess_bwd<., 3> then updates the
+// rows with instances.  Same adam_elem as everywhere: the two kernels together equal k_preprocess_bwd<., 1> bit for bit.
+__global__ __launch_bounds__(256) void k_adam_culled_rows(int P, int sh_stride, const uint32_t* __restrict__ tiles_touched,
+                                                          const GsrAdamArgs A) {
+  __shared__ int32_t culled[256];
+  const size_t row0 = (size_t)blockIdx.x * 256;
+  const int rows = (int)min((size_t)256, (size_t)P - row0);
+  const bool mine = (int)threadIdx.x < rows && tiles_touched[row0 + threadIdx.x] == 0;
+  culled[threadIdx.x] = mine ? 1 : 0;
+  __syncthreads();
+  if (mine) {
+    const size_t idx = row0 + threadIdx.x;
+    const float z[4] = {0.f, 0.f, 0.f, 0.f};
+    adam_row<1, 3>(A, 0, idx, z);
+    adam_row<1, 3>(A, 1, idx, z);
+    adam_row<1, 1>(A, 3, idx, z);
+    adam_row<1, 3>(A, 4, idx, z);
+    adam_row<1, 4>(A, 5, idx, z);
+  }
+  if (sh_stride == 0) return;
+  const int S = 3 * sh_stride;
+  const int nflt = rows * S, n4 = nflt >> 2;
+  const int dr = 1024 / S, dcol = 1024 - dr * S;
+  int r = (threadIdx.x * 4) / S, c = threadIdx.x * 4 - r * S;
+  float* Pg = A.p[2] + row0 * S;
+  float* Mg = A.m[2] + row0 * S;
+  float* Vg = A.v[2] + row0 * S;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    // a 16-B piece is ours only if EVERY row it touches is culled; a piece shared with a row that has instances belongs,
+    // whole, to k_preprocess_bwd<., 3> (which gives our elements in it the same zero-gradient update)
+    const int r_end = min(r + (c + 3 >= S ? 1 : 0), rows - 1);
+    if (culled[r] && culled[r_end]) {
+      const gsr_f4 p4 = gsr_ld_stream(Pg + 4 * (size_t)i), m4 = gsr_ld_stream(Mg + 4 * (size_t)i),
+                   v4 = gsr_ld_stream(Vg + 4 * (size_t)i);
+      float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) adam_elem<1>(pp[k], mm[k], vv[k], 0.f, A, 2);
+      gsr_st_stream(Pg + 4 * (size_t)i, gsr_f4{pp[0], pp[1], pp[2], pp[3]});
+      gsr_st_stream(Mg + 4 * (size_t)i, gsr_f4{mm[0], mm[1], mm[2], mm[3]});
+      gsr_st_stream(Vg + 4 * (size_t)i, gsr_f4{vv[0], vv[1], vv[2], vv[3]});
+    }
+    r += dr; c += dcol;
+    if (c >= S) { c -= S; r++; }
+  }
+  for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {
+    const int r2 = e / S;
+    if (culled[r2]) {
+      float pv = Pg[e], mv = Mg[e], vvv = Vg[e];
+      adam_elem<1>(pv, mv, vvv, 0.f, A, 2);
+      Pg[e] = pv; Mg[e] = mv; Vg[e] = vvv;
+    }
+  }
+}
+
+void gsr_launch_adam_culled_rows(int P, int sh_stride, const char* geom, const GsrGeomLayout& L, const GsrAdamArgs& A,
+                                 hipStream_t st) {
+  GSR_LAUNCH("adam_culled_rows", k_adam_culled_rows, dim3((P + 255) / 256), dim3(256), 0, st, P, sh_stride,
+             (const uint32_t*)(geom + L.tiles_touched), A);
 }
 
 __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
@@ -1060,6 +1126,8 @@ int gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, con
     if (stage) GSR_PRE_BWD(true, 0); else GSR_PRE_BWD(false, 0);
   } else if (adam_mode == 2) {
     if (stage) GSR_PRE_BWD(true, 2); else GSR_PRE_BWD(false, 2);
+  } else if (adam_mode == 3) {
+    if (stage) GSR_PRE_BWD(true, 3); else GSR_PRE_BWD(false, 3);
   } else {
     if (stage) GSR_PRE_BWD(true, 1); else GSR_PRE_BWD(false, 1);
   }

@@ -80,6 +80,7 @@ EXPORTS = {
     "gsr_backward_adam": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.POINTER(gsr_grads), C.POINTER(gsr_fused_adam), C.c_void_p]),
+    "gsr_adam_step_culled_rows": (C.c_int, [C.POINTER(gsr_gaussians), C.c_void_p, C.POINTER(gsr_fused_adam), C.c_void_p]),
     "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_geometry_views": (C.c_int, [C.c_void_p, C.c_int32] + [C.POINTER(C.c_void_p)] * 6),
     "gsr_debug_wave_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -55,14 +55,23 @@ _fused_optimizer = None
 fused_backward_count = 0
 
 
-def fuse_optimizer_into_next_backward(optimizer):
+_split_rows = False
+_side_streams = {}
+
+
+def fuse_optimizer_into_next_backward(optimizer, split_rows=False):
     """`optimizer`: a FusedAdam / SparseGaussianAdam over the model's six parameter groups (named xyz, f_dc, f_rest, opacity,
     scaling, rotation as in reference scene/gaussian_model.py:160-168), or None to cancel.  The next backward of a rasterizer
     call that received exactly those parameters (raw-parameter call form, dc / rest separate) then applies the Adam update
     itself and returns no gradient for them; any other backward leaves the hand-off in place, so the caller can check
-    `fuse_pending()` afterwards and fall back to optimizer.step()."""
-    global _fused_optimizer
+    `fuse_pending()` afterwards and fall back to optimizer.step().
+    split_rows (dense Adam only): the rows WITHOUT tile instances in that forward (exact zero gradient) are updated by
+    gsr_adam_step_culled_rows on a side stream while the compositing backward - bound by VALU issue, the HBM idle - runs on
+    the caller's stream; the backward's last kernel then updates the rows with instances.  Bit-identical to the unsplit update;
+    later work on the caller's stream is ordered behind both halves."""
+    global _fused_optimizer, _split_rows
     _fused_optimizer = optimizer
+    _split_rows = bool(split_rows) and optimizer is not None
 
 
 def fuse_pending():
@@ -72,9 +81,10 @@ def fuse_pending():
 _GROUP_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
 
 
-def _fused_adam_struct(opt, tensors):
+def _fused_adam_struct(opt, tensors, advance=True, rows=None):
     """gsr_fused_adam for optimizer `opt` if its six groups are exactly `tensors` (means3D, dc, sh, opacities, scales,
-    rotations as saved by the forward), else None."""
+    rotations as saved by the forward), else None.  advance=False: the step numbers this update WILL carry, without
+    counting it yet (the early culled-rows half of a split update)."""
     groups = {g.get("name"): g for g in opt.param_groups}
     if any(n not in groups for n in _GROUP_ORDER):
         return None
@@ -96,16 +106,17 @@ def _fused_adam_struct(opt, tensors):
             st["step"] = torch.tensor(0.0)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        if not sparse:
+        if not sparse and advance:
             st["step"] += 1
         fa.exp_avg[i] = st["exp_avg"].data_ptr() if p.numel() else None
         fa.exp_avg_sq[i] = st["exp_avg_sq"].data_ptr() if p.numel() else None
         fa.lr[i] = float(groups[n]["lr"])
-        fa.step[i] = int(st["step"]) if not sparse else 1
+        fa.step[i] = (int(st["step"]) + (0 if advance else 1)) if not sparse else 1
         keep.append(st)
     g0 = opt.param_groups[0]
     b1, b2 = (0.9, 0.999) if sparse else g0["betas"]
-    fa.beta1, fa.beta2, fa.eps, fa.sparse = float(b1), float(b2), float(g0["eps"]), 1 if sparse else 0
+    fa.beta1, fa.beta2, fa.eps = float(b1), float(b2), float(g0["eps"])
+    fa.sparse = 1 if sparse else (2 if rows == "with_instances" else 0)
     return fa, keep
 
 
@@ -302,16 +313,29 @@ class _RasterizeGaussians(torch.autograd.Function):
                 global _fused_optimizer, fused_backward_count
                 fused = None
                 if _fused_optimizer is not None and ctx.raw_activations and dc is not None and colors_precomp is None:
-                    fused = _fused_adam_struct(_fused_optimizer, (means3D, dc, sh, opacities, scales, rotations))
+                    split = _split_rows and not isinstance(_fused_optimizer, SparseGaussianAdam)
+                    fused = _fused_adam_struct(_fused_optimizer, (means3D, dc, sh, opacities, scales, rotations),
+                                               rows="with_instances" if split else None)
                 try:
                     if fused is not None:
                         # the optimizer step rides in the backward's last kernel: no gradient leaves the device registers
                         _fused_optimizer = None
                         fused_backward_count += 1
+                        if split:
+                            # the culled rows' half: needs only the forward's state, so it runs beside the compositing backward
+                            side = _side_streams.get(dev.index)
+                            if side is None:
+                                side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+                            side.wait_stream(cur)
+                            with torch.cuda.stream(side):
+                                _C.check(lib.gsr_adam_step_culled_rows(C.byref(g), _C.ptr(geom), C.byref(fused[0]),
+                                                                       _stream()))
                         _C.check(lib.gsr_backward_adam(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom),
                                                        _C.ptr(binning), _C.ptr(img), R, _C.ptr(grad_color),
                                                        _C.ptr(grad_invdepth), _C.ptr(scratch), scratch.numel(), C.byref(gr),
                                                        C.byref(fused[0]), _stream()))
+                        if split:
+                            cur.wait_stream(side)      # whatever follows on this stream sees both halves of the update
                         ws.stream = cur
                         return (None, d_means2D, None, None, None, None, None, None, None, None, None, None)
                     _C.check(lib.gsr_backward(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom), _C.ptr(binning),

@@ -23,6 +23,10 @@ class Trainer:
         # (gsr_backward_adam) whenever nothing sits between backward and step: one rank, one view per step, no densification
         # due.  Same arithmetic, bit for bit; the 59 floats per Gaussian of gradients never leave the kernel.
         self.fuse_step = optimizer in ("hip_fused", "hip_sparse_fused")
+        # dense folded Adam: the rows WITHOUT tile instances (exact zero gradient; a third of the synthetic bench scene, most
+        # of a room-scale capture) are updated on a side stream while the compositing kernels run - those are bound by VALU
+        # issue and leave the HBM idle (gsr_adam_step_culled_rows; bit-identical to the unsplit update)
+        self.split_rows = self.fuse_step
         optimizer = {"hip_fused": "hip", "hip_sparse_fused": "hip_sparse"}.get(optimizer, optimizer)
         self.optimizer_kind = optimizer
         # like the reference, the model owns the optimizer and the densification statistics (gaussian_model.py:155-176)
@@ -82,7 +86,7 @@ class Trainer:
                 and self.separate_sh
             if fold:
                 import diff_gaussian_rasterization as dgr
-                dgr.fuse_optimizer_into_next_backward(self.optimizer)
+                dgr.fuse_optimizer_into_next_backward(self.optimizer, split_rows=self.split_rows)
             loss.backward()                                                                      # .grad accumulates
             if fold and dgr.fuse_pending():
                 dgr.fuse_optimizer_into_next_backward(None)     # the rasterizer could not take it: plain step below

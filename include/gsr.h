@@ -175,6 +175,10 @@ int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* r
  *   sparse = 0: torch.optim.Adam semantics (bias correction; `step` = 1-based step number AFTER this update), every row.
  *   sparse = 1: SparseGaussianAdam.step(radii > 0, P) semantics (reference train.py:173-176): rows with radii == 0 untouched,
  *               no bias correction.
+ *   sparse = 2: as 0, but only the rows that have tile instances in this forward are updated here; the others (their gradient
+ *               is exactly zero) must get their update from gsr_adam_step_culled_rows with the same `opt` values - a call
+ *               that needs nothing from the backward and can therefore run on another stream while the compositing kernels
+ *               (bound by VALU issue, not by HBM) are busy.  The pair equals sparse = 0 bit for bit.
  * grads->dL_dmeans2D is still written (densification statistics, scene/gaussian_model.py:431-433); the other members of `grads`
  * are ignored.  Same arithmetic as gsr_backward followed by gsr_adam_step / gsr_sparse_adam_step, bit for bit. */
 typedef struct gsr_fused_adam {
@@ -189,6 +193,12 @@ int gsr_backward_adam(const gsr_settings* s, const gsr_gaussians* g, const int32
                       const void* binning_state, const void* image_state, int64_t num_rendered, const float* dL_dcolor,
                       const float* dL_dinvdepth, void* scratch, size_t scratch_bytes, const gsr_grads* grads,
                       const gsr_fused_adam* opt, void* stream);
+
+/* Dense Adam update (zero gradient: moments decay, the parameter follows its momentum) of the rows that reached no tile in the
+ * forward whose geometry state is given; companion of gsr_backward_adam(opt->sparse = 2).  May be enqueued on any stream once
+ * the forward call that filled `geometry_state` has been enqueued and that stream waits for it; the caller orders it before the
+ * next forward.  `g` and `opt` as for gsr_backward_adam (same `step` values). */
+int gsr_adam_step_culled_rows(const gsr_gaussians* g, const void* geometry_state, const gsr_fused_adam* opt, void* stream);
 
 /* GaussianRasterizer.markVisible (near-plane test).  present[P] uint8. */
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream);

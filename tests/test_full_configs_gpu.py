@@ -34,7 +34,7 @@ def _tile_mask(W, H, n, seed):
     return tiles, mask
 
 
-def _check_sampled(ref, out, mask, W, H, depth=True):
+def _check_sampled(ref, out, mask, W, H, depth=True, ref32=None):
     """Colour / inverse depth within 2e-5 on >= 99.99 % of the sampled PIXELS - but never fewer than one pixel allowed out:
     a sample of a few thousand pixels is smaller than 1 / 0.01 %, and a single fp32-vs-float64 flip of a blending threshold
     (alpha < 1/255, T < 1e-4: SURVEY.md 7 "Numerics") moves one pixel by up to its Gaussian's contribution; such an outlier is
@@ -42,6 +42,12 @@ def _check_sampled(ref, out, mask, W, H, depth=True):
     sel = mask.bool()[0]
     d = (ref["color"].double() - out["color"].double()).abs().amax(dim=0)[sel]
     allowed = max(1, int((1.0 - FWD_FRAC) * d.numel()))
+    if ref32 is not None:
+        # calibration ("float32 oracle run calibrates tolerance"): the oracle ITSELF evaluated in float32
+        # flips the same kind of thresholds against its float64 run; with long lists (C4: ~850 entries per tile, AA) that is
+        # more than 0.01 % of the pixels, and the HIP path is held to "no worse than twice the fp32 oracle, plus one"
+        d32 = (ref["color"].double() - ref32["color"].double()).abs().amax(dim=0)[sel]
+        allowed = max(allowed, 2 * int((d32 > FWD_ATOL).sum()) + 1)
     assert int((d > FWD_ATOL).sum()) <= allowed and float(d.max()) < 5e-3, (int((d > FWD_ATOL).sum()), float(d.max()))
     if depth:
         dd = (ref["invdepth"].double() - out["invdepth"].double()).abs()[0][sel]
@@ -79,8 +85,9 @@ def test_config4_full_size_properties_and_oracle_tiles():
     gc, gd = gc * mask, gd * mask
     out = run_hip(raw, cam, 3, bg, antialiasing=True, gc=gc, gd=gd)
     ref = run_oracle(raw, cam, 3, bg, torch.float64, antialiasing=True, gc=gc, gd=gd, tiles=tiles)
-    _check_sampled(ref, out, mask, W, H)
-    del ref
+    ref32 = run_oracle(raw, cam, 3, bg, torch.float32, antialiasing=True, tiles=tiles)
+    _check_sampled(ref, out, mask, W, H, ref32=ref32)
+    del ref, ref32
     # linearity of the backward in the upstream gradient (whole frame, inverse-depth gradient included)
     gcf, gdf = upstream_grads(H, W, seed=43)
     a = run_hip(raw, cam, 3, bg, antialiasing=True, gc=gcf, gd=gdf)

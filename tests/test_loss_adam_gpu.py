@@ -159,3 +159,40 @@ def test_optimizer_step_folded_into_backward_is_bit_identical(kind):
     # and the parameters did move
     ref = GaussianModel.from_raw(make_gaussians(3000, 3, seed=93, scale_factor=0.7).to("cuda"))
     assert not torch.equal(ref._features_rest, runs[True][0]["f_rest"][0])
+
+
+def test_split_dense_adam_culled_rows_on_side_stream_is_bit_identical():
+    """hip_fused splits the dense update: rows without tile instances on a side stream during the compositing kernels
+    (gsr_adam_step_culled_rows, launched by the rasterizer's backward), rows with instances in the backward (gsr_backward_adam, sparse = 2).  Against the unsplit
+    folded update (Trainer.split_rows off) on a scene where a good part of the Gaussians is off-screen."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import make_gaussians, fibonacci_cameras, GaussianModel, Trainer
+    cams = fibonacci_cameras(3, 144, 96, seed=191, device="cuda")
+    bg = torch.zeros(3, device="cuda")
+    pipe = PipelineParams()
+    def scene(seed):
+        raw = make_gaussians(5000, 3, seed=seed, scale_factor=0.6)
+        raw.xyz[::3] *= 3.0                      # a third of the cloud far outside the frustum
+        return raw
+    teacher = GaussianModel.from_raw(scene(192).to("cuda"), requires_grad=False)
+    with torch.no_grad():
+        gts = {i: render(c, teacher, pipe, bg)["render"].clone() for i, c in enumerate(cams)}
+    out = {}
+    for split in (False, True):
+        model = GaussianModel.from_raw(scene(193).to("cuda"))
+        tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True, optimizer="hip_fused")
+        assert tr.split_rows
+        tr.split_rows = split
+        culled = 0
+        for it in range(6):
+            o = tr.step(it % 3)
+            culled += int((o["radii"] == 0).sum())
+        tr.finish()
+        torch.cuda.synchronize()
+        assert culled > 3000
+        out[split] = [(p.detach().clone(), tr.optimizer.state[p]["exp_avg"].clone(), tr.optimizer.state[p]["exp_avg_sq"].clone())
+                      for p in model.parameters()]
+    for a, b in zip(out[False], out[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), float((x - y).abs().max())
