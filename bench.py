@@ -241,6 +241,9 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views per rank per optimizer step (gradient accumulation; default 1 = the reference's batch-1 step). "
                          "Amortises the N>1 gradient exchange and Adam over k views; value still counts view-iterations")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "visible_rows", "sharded"],
+                    help="N>1 gradient exchange: one all-reduce per leaf tensor (north-star schedule); the same restricted to the "
+                         "rows some rank saw; or reduce-scatter -> Adam on a 1/N row shard -> all-gather (DESIGN.md 5)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: exchange all gradients on the main stream (default overlaps the SH exchange + Adam with the next "
                          "step's geometry stages; same results, DESIGN.md 5)")
@@ -260,7 +263,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import socket
         import subprocess
-        if torch.cuda.device_count() < args.gpus:      # (device_count does not initialise the GPU)
+        if torch.cuda.device_count() < args.gpus and not os.environ.get("BENCH_SHARE_GPU"):   # (does not initialise the GPU)
             print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} visible", file=sys.stderr)
             sys.exit(2)
         with socket.socket() as so:
@@ -296,7 +299,8 @@ def main():
     trainer = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=args.optimizer,
                       loss=args.loss, separate_sh=not args.concat_sh, depth_targets=depth_gts,
                       depth_weight=1.0 if depth_gts is not None else 0.0,
-                      overlap_comm=False if args.no_overlap else (True if args.overlap else None))
+                      overlap_comm=False if args.no_overlap else (True if args.overlap else None),
+                      exchange=args.exchange)
     if args.densify:
         # cameras_extent of the reference = 1.1 x radius of the camera centres (scene/dataset_readers.py getNerfppNorm)
         trainer.enable_densification(extent=1.1 * 4.0, from_iter=args.densify_from)
@@ -369,7 +373,7 @@ def main():
                    "gaussians": P, "gaussians_final": int(model.get_xyz.shape[0]), "densify": bool(args.densify),
                    "sh_degree": cfg["deg"], "width": W, "height": H, "views": len(cams),
                    "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}",
-                   "views_per_rank_per_step": k, "overlap_comm": bool(trainer.overlap_comm),
+                   "views_per_rank_per_step": k, "overlap_comm": bool(trainer.overlap_comm), "exchange": trainer.exchange,
                    "loss": "L1 + 0.2 DSSIM (" + ("HIP fused SSIM" if args.loss == "hip" else "torch conv2d SSIM") + ")",
                    "optimizer": {"hip": "Adam, one-launch HIP kernel (torch.optim.Adam semantics)",
                                  "hip_fused": "Adam (torch.optim.Adam semantics) folded into the rasterizer backward",

@@ -11,7 +11,8 @@ from .parallel import GradBucket, reduce_densification_stats
 
 class Trainer:
     def __init__(self, model, cameras, gt_images, render_fn, pipe, bg, lambda_dssim=0.2, world=1, rank=0,
-                 optimizer="hip", loss="hip", depth_targets=None, depth_weight=0.0, separate_sh=False, overlap_comm=None):
+                 optimizer="hip", loss="hip", depth_targets=None, depth_weight=0.0, separate_sh=False, overlap_comm=None,
+                 exchange="allreduce"):
         """optimizer: "hip" (one-launch HIP Adam, default-optimizer semantics), "hip_sparse" (SparseGaussianAdam, the
         reference's accelerated choice) or "torch" (torch.optim.Adam; CPU tests).  loss: "hip" (fused SSIM kernels) or
         "torch" (pure-PyTorch ssim; CPU tests)."""
@@ -33,13 +34,32 @@ class Trainer:
         self.optimizer = model.training_setup(optimizer=optimizer)
         self.loss_fn = {"hip": training_loss_fused, "torch": training_loss}[loss]
         self.bucket = GradBucket(model.parameters()) if world > 1 else None
+        # N > 1 gradient exchange: "allreduce" (one all-reduce per leaf, every rank runs the whole update),
+        # "visible_rows" (the same, restricted to the rows some rank saw), "sharded" (reduce-scatter -> Adam on a 1/N row shard
+        # -> all-gather of the parameters; dense optimizers, no densification yet: the moments live per shard)
+        if exchange not in ("allreduce", "visible_rows", "sharded"):
+            raise ValueError(exchange)
+        self.exchange = exchange if world > 1 else "allreduce"
+        self.sharded = None
+        if self.exchange == "sharded":
+            if optimizer not in ("hip", "torch"):
+                raise ValueError("exchange='sharded' needs a dense optimizer ('hip' or 'torch')")
+            from .parallel import ShardedStep
+            if optimizer == "torch":
+                mk = lambda groups: torch.optim.Adam(groups, lr=0.0, eps=1e-15)      # noqa: E731
+            else:
+                from diff_gaussian_rasterization import FusedAdam
+                mk = lambda groups: FusedAdam(groups, lr=0.0, eps=1e-15)             # noqa: E731
+            self.sharded = ShardedStep(model, mk, world, rank)
+            self.optimizer = self.sharded.optimizer
         self.depth_targets, self.depth_weight = depth_targets, depth_weight
         # reference train.py:106 passes separate_sh=SPARSE_ADAM_AVAILABLE: dc / rest go to the rasterizer unconcatenated
         self.separate_sh = separate_sh
         # Overlap of the cross-rank exchange with the next step's geometry stages: needs the HIP device, the
         # HIP optimizers (they step parameter groups separately) and dc / rest passed unconcatenated (separate_sh), because a
         # torch.cat of the SH tensors would read them on the main stream while their update is still in flight.
-        can_overlap = optimizer in ("hip", "hip_sparse") and separate_sh and model.get_xyz.is_cuda
+        can_overlap = optimizer in ("hip", "hip_sparse") and separate_sh and model.get_xyz.is_cuda and \
+            self.exchange == "allreduce"
         # default: on for N > 1.  On one GPU it can be requested, but it buys nothing (measured 2.22 vs 2.21 ms/step at C3: the
         # Adam kernel fills the machine, the small geometry kernels just queue behind it); what it hides is COMMUNICATION.
         self.overlap_comm = (can_overlap and world > 1) if overlap_comm is None else (bool(overlap_comm) and can_overlap)
@@ -110,9 +130,14 @@ class Trainer:
         if self.overlap_comm and not self._densify_due():
             self._exchange_and_step_overlapped(vis, radii)
             return self.last
+        if self.sharded is not None:
+            if self.densify is not None:
+                raise NotImplementedError("exchange='sharded' with densification: the Adam moments live per row shard")
+            self.sharded.step()
+            return self.last
         with torch.no_grad():
             if self.bucket is not None:
-                self.bucket.all_reduce_mean(self.world)
+                self.bucket.all_reduce_mean(self.world, visible=vis if self.exchange == "visible_rows" else None)
             if self.densify is not None:
                 # the reference densifies between backward and the optimizer step (train.py:155-168 before :170): the
                 # replaced Parameters carry no gradient, so the step that follows skips them, exactly like there

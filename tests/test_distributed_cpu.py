@@ -33,7 +33,7 @@ def _scene():
     return raw, cams, gts
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, exchange="allreduce", steps=1):
     for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -45,13 +45,16 @@ def _worker(rank, world, port, out_dir):
     assert (r, w) == (rank, world)
     raw, cams, gts = _scene()
     model = GaussianModel.from_raw(raw)
-    tr = Trainer(model, cams, gts, _oracle_render, PipelineParams(), torch.zeros(3), world=w, rank=r, optimizer="torch", loss="torch")
+    tr = Trainer(model, cams, gts, _oracle_render, PipelineParams(), torch.zeros(3), world=w, rank=r, optimizer="torch", loss="torch",
+                 exchange=exchange)
     mine = shard_views(len(cams), r, w)
-    for v in mine[:1]:
+    for v in mine[:steps]:
         tr.step(v)
     reduce_densification_stats(tr.xyz_gradient_accum, tr.denom, tr.max_radii2D, w)
     torch.save({"params": [p.detach().clone() for p in model.parameters()], "accum": tr.xyz_gradient_accum,
-                "denom": tr.denom, "maxr": tr.max_radii2D, "views": mine}, os.path.join(out_dir, f"r{rank}.pt"))
+                "denom": tr.denom, "maxr": tr.max_radii2D, "views": mine,
+                "moment_bytes": tr.sharded.moment_bytes() if tr.sharded is not None else None},
+               os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -104,3 +107,70 @@ def test_two_rank_step_equals_mean_gradient_step(tmp_path):
     for pa, p in zip(a["params"], model.parameters()):
         assert torch.allclose(pa, p.detach(), atol=1e-6, rtol=1e-5)
     assert torch.allclose(a["accum"], accum, atol=1e-6) and torch.equal(a["denom"], denom) and torch.equal(a["maxr"], maxr)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("exchange", ["sharded", "visible_rows"])
+def test_sharded_and_visible_row_exchanges_equal_the_all_reduce_schedule(tmp_path, exchange):
+    """reduce-scatter -> Adam on a 1/N row shard -> all-gather, and the visible-rows-only all-reduce, against the plain
+    all-reduce schedule over two optimizer steps (so the second step sees the first one's moments): identical parameters on
+    both ranks and across schedules, bit for bit; the sharded schedule keeps half of the Adam moments per rank.  120 rows on
+    2 ranks and, for the left-over rows' path, 121 rows."""
+    outs = {}
+    for k, ex in enumerate(("allreduce", exchange)):
+        d = tmp_path / ex
+        d.mkdir()
+        port = 31000 + (os.getpid() % 2000) + 7 * k
+        mp.spawn(_worker, args=(2, port, str(d), ex, 2), nprocs=2, join=True)
+        outs[ex] = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(2)]
+    for ex, (a, b) in outs.items():
+        for pa, pb in zip(a["params"], b["params"]):
+            assert torch.equal(pa, pb), ex
+    for pa, pb in zip(outs["allreduce"][0]["params"], outs[exchange][0]["params"]):
+        assert torch.equal(pa, pb)
+    if exchange == "sharded":
+        full = sum(p.numel() for p in outs["allreduce"][0]["params"]) * 4 * 2
+        assert outs["sharded"][0]["moment_bytes"] == full // 2
+
+
+def test_sharded_step_handles_rows_not_divisible_by_world(tmp_path):
+    """P = 121 on 2 ranks: 60-row shards plus one left-over row that both ranks update from the all-reduced gradient."""
+    d = tmp_path / "odd"
+    d.mkdir()
+    port = 33000 + (os.getpid() % 2000)
+    mp.spawn(_worker_odd, args=(2, port, str(d)), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(d, f"r{r}.pt")) for r in range(2))
+    for x, y, z in zip(a["sharded"], b["sharded"], a["allreduce"]):
+        assert torch.equal(x, y) and torch.equal(x, z)
+
+
+def _worker_odd(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from scene_utils import init_from_env, GaussianModel, GradBucket, ShardedStep, make_gaussians
+    init_from_env("gloo")
+    res = {}
+    for mode in ("allreduce", "sharded"):
+        model = GaussianModel.from_raw(make_gaussians(121, 1, seed=5))
+        mk = lambda groups: torch.optim.Adam(groups, lr=0.0, eps=1e-15)      # noqa: E731
+        if mode == "sharded":
+            st = ShardedStep(model, mk, world, rank)
+        else:
+            opt, bucket = mk(model.param_groups()), GradBucket(model.parameters())
+        for it in range(3):
+            gen = torch.Generator().manual_seed(1000 * it + rank)
+            for p in model.parameters():
+                p.grad = torch.randn(p.shape, generator=gen)
+            if mode == "sharded":
+                st.step()
+            else:
+                bucket.all_reduce_mean(world)
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+        res[mode] = [p.detach().clone() for p in model.parameters()]
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
