@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--hi-prio", action="store_true",
                     help="run the training loop on a high-priority stream (the side stream of --overlap stays at normal "
                          "priority, so the small binning kernels are dispatched ahead of the bandwidth-bound SH update)")
+    ap.add_argument("--split-rows", action="store_true",
+                    help="hip_fused: update the rows without tile instances on a side stream beside the compositing backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--forward-mode", default=None, choices=["async", "sync"],
@@ -301,6 +303,7 @@ def main():
                       depth_weight=1.0 if depth_gts is not None else 0.0,
                       overlap_comm=False if args.no_overlap else (True if args.overlap else None),
                       exchange=args.exchange)
+    trainer.split_rows = bool(args.split_rows)
     if args.densify:
         # cameras_extent of the reference = 1.1 x radius of the camera centres (scene/dataset_readers.py getNerfppNorm)
         trainer.enable_densification(extent=1.1 * 4.0, from_iter=args.densify_from)

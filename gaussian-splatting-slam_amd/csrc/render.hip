@@ -599,10 +599,10 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
                            const uint32_t* point_list, const float4* rec, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dinvdepth,
                            const uint32_t* slot_of_pos, float4* igrad, hipStream_t st) {
-  // One wave per tile needs enough tiles to keep 1024 SIMDs busy: below ~2 tiles per SIMD the four-waves-per-tile form
+  // One wave per tile needs enough tiles to keep 1024 SIMDs busy: below ~6 tiles per SIMD (720p: 3600 tiles) the four-waves-per-tile form
   // (same results up to summation order inside a tile) has the shorter critical path.  GSR_BWD_FORM=quad|tile forces one.
   static const char* form = getenv("GSR_BWD_FORM");
-  const bool quad = form ? !strcmp(form, "quad") : tiles < 2048;
+  const bool quad = form ? !strcmp(form, "quad") : tiles < 6000;
   if (!quad || (form && !strcmp(form, "tile"))) {
     if (dL_dinvdepth)
       GSR_LAUNCH("render_bwd", k_render_bwd_tile<true>, dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height,

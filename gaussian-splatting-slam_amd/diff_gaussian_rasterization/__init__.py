@@ -169,7 +169,7 @@ def _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotatio
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_C.raw_stream())
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -195,7 +195,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # can follow is decided by the caller, rasterize_gaussians(), and arrives as `for_backward`)
         needs_grad = bool(for_backward)
 
-        with torch.cuda.device(dev):
+        with _C.on_device(dev):
             pool = _ws.pool(dev)
             pool.poll()                      # instance counts of earlier frames that have arrived meanwhile
             ws = pool.acquire()              # state buffers of this forward (-> backward): grow-only, recycled
@@ -290,7 +290,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         def like(t, *shape):
             return torch.empty(*shape, dtype=torch.float32, device=dev) if t is not None else None
 
-        with torch.cuda.device(dev):
+        with _C.on_device(dev):
             d_means3D = torch.empty(P, 3, dtype=torch.float32, device=dev)
             d_means2D = torch.empty(P, 3, dtype=torch.float32, device=dev)
             d_opac = torch.empty(opacities.shape if opacities is not None else (P, 1), dtype=torch.float32, device=dev)
@@ -301,9 +301,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_rot = like(rotations, P, 4)
             d_cov = like(cov3D_precomp, P, 6)
             if P > 0:
-                cur = torch.cuda.current_stream()
+                cur = _C.raw_stream()
                 if ws.stream is not None and ws.stream != cur:
-                    cur.wait_stream(ws.stream)
+                    torch.cuda.current_stream().wait_stream(torch.cuda.ExternalStream(ws.stream))
                 s, keep = _settings_struct(rs, dev)
                 g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                   ctx.raw_activations)
@@ -326,7 +326,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                             side = _side_streams.get(dev.index)
                             if side is None:
                                 side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
-                            side.wait_stream(cur)
+                            side.wait_stream(torch.cuda.current_stream())
                             with torch.cuda.stream(side):
                                 _C.check(lib.gsr_adam_step_culled_rows(C.byref(g), _C.ptr(geom), C.byref(fused[0]),
                                                                        _stream()))
@@ -335,7 +335,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                        _C.ptr(grad_invdepth), _C.ptr(scratch), scratch.numel(), C.byref(gr),
                                                        C.byref(fused[0]), _stream()))
                         if split:
-                            cur.wait_stream(side)      # whatever follows on this stream sees both halves of the update
+                            torch.cuda.current_stream().wait_stream(side)   # what follows here sees both halves of the update
                         ws.stream = cur
                         return (None, d_means2D, None, None, None, None, None, None, None, None, None, None)
                     _C.check(lib.gsr_backward(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom), _C.ptr(binning),

@@ -49,7 +49,7 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self.geom = self.img = self.binning = self.scratch = None
-        self.stream = None            # stream the last user enqueued on
+        self.stream = None            # raw hipStream_t (int) the last user enqueued on
 
     def _grow(self, name, nbytes, slack=1.0):
         t = getattr(self, name)
@@ -103,7 +103,7 @@ class Pool:
 
     # ---- workspaces ----
     def acquire(self) -> Workspace:
-        stream = torch.cuda.current_stream(self.device)
+        stream = _C.raw_stream(self.device.index)
         with self.lock:
             ws = None
             for i, w in enumerate(self.free):     # prefer one last used on this stream (plain stream order protects it)
@@ -115,7 +115,8 @@ class Pool:
         if ws is None:
             ws = Workspace(self.device)
         elif ws.stream is not None and ws.stream != stream:
-            stream.wait_stream(ws.stream)         # its previous user may still be running on another stream
+            # its previous user may still be running on another stream
+            torch.cuda.current_stream(self.device).wait_stream(torch.cuda.ExternalStream(ws.stream))
         ws.stream = stream
         return ws
 

@@ -72,7 +72,7 @@ class FusedAdam(_GsrAdamBase):
                 st["step"] += 1
             n, vp, vg, vm, vv, num, lr = _arrays(ps[sl], gs[sl], ms[sl], vs[sl], lrs[sl])
             steps = (C.c_int64 * n)(*[int(st["step"]) for st in states[sl]])
-            with torch.cuda.device(ps[0].device):
+            with _C.on_device(ps[0].device):
                 _C.check(lib.gsr_adam_step(n, vp, vg, vm, vv, num, lr, steps, float(b1), float(b2), float(g0["eps"]),
                                            _C._stream()))
 
@@ -92,6 +92,6 @@ class SparseGaussianAdam(_GsrAdamBase):
         for i in range(0, len(ps), 8):
             sl = slice(i, i + 8)
             n, vp, vg, vm, vv, num, lr = _arrays(ps[sl], gs[sl], ms[sl], vs[sl], lrs[sl])
-            with torch.cuda.device(ps[0].device):
+            with _C.on_device(ps[0].device):
                 _C.check(lib.gsr_sparse_adam_step(n, vp, vg, vm, vv, num, lr, int(N), _C.ptr(vis), 0.9, 0.999,
                                                   float(g0["eps"]), _C._stream()))

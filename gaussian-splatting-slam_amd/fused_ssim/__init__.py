@@ -52,7 +52,7 @@ class _FusedL1SSIMLoss(torch.autograd.Function):
         nblk = int(lib.gsr_fused_loss_blocks(planes, H, W))
         partials = torch.empty(nblk, 2, dtype=torch.float32, device=a.device)
         loss = torch.empty((), dtype=torch.float32, device=a.device)
-        with torch.cuda.device(a.device):
+        with _C.on_device(a.device):
             _C.check(lib.gsr_fused_l1_ssim_forward(planes, H, W, C1, C2, float(lambda_dssim), _C.ptr(a), _C.ptr(b),
                                                    _C.ptr(parts[0]), _C.ptr(parts[1]), _C.ptr(parts[2]),
                                                    _C.ptr(partials), _C.ptr(loss), _C._stream()))
@@ -68,7 +68,7 @@ class _FusedL1SSIMLoss(torch.autograd.Function):
         planes = a.numel() // (H * W)
         g = g.detach().float().contiguous()                # device scalar dL/dloss: read by the kernel, never by the host
         out = torch.empty_like(a)
-        with torch.cuda.device(a.device):
+        with _C.on_device(a.device):
             _C.check(lib.gsr_fused_l1_ssim_backward(planes, H, W, ctx.lam, _C.ptr(a), _C.ptr(b), _C.ptr(g), _C.ptr(p0),
                                                     _C.ptr(p1), _C.ptr(p2), _C.ptr(out), _C._stream()))
         return out, None, None

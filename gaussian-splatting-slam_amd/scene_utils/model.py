@@ -163,7 +163,7 @@ def add_densification_stats(self, viewspace_point_tensor, update_filter, radii=N
         if g.is_cuda and radii is not None:
             from diff_gaussian_rasterization import _C
             P = int(g.shape[0])
-            with torch.cuda.device(g.device):
+            with _C.on_device(g.device):
                 _C.check(_C.lib().gsr_densification_stats(P, _C.ptr(g.contiguous()), _C.ptr(radii.contiguous()),
                                                           _C.ptr(self.xyz_gradient_accum), _C.ptr(self.denom),
                                                           _C.ptr(self.max_radii2D), _C._stream()))

@@ -27,7 +27,7 @@ class Trainer:
         # dense folded Adam: the rows WITHOUT tile instances (exact zero gradient; a third of the synthetic bench scene, most
         # of a room-scale capture) are updated on a side stream while the compositing kernels run - those are bound by VALU
         # issue and leave the HBM idle (gsr_adam_step_culled_rows; bit-identical to the unsplit update)
-        self.split_rows = self.fuse_step
+        self.split_rows = False          # (opt-in: measured a wash at C3 on one MI355X, see profiles/README.md)
         optimizer = {"hip_fused": "hip", "hip_sparse_fused": "hip_sparse"}.get(optimizer, optimizer)
         self.optimizer_kind = optimizer
         # like the reference, the model owns the optimizer and the densification statistics (gaussian_model.py:155-176)
@@ -108,8 +108,11 @@ class Trainer:
                 import diff_gaussian_rasterization as dgr
                 dgr.fuse_optimizer_into_next_backward(self.optimizer, split_rows=self.split_rows)
             loss.backward()                                                                      # .grad accumulates
-            if fold and dgr.fuse_pending():
-                dgr.fuse_optimizer_into_next_backward(None)     # the rasterizer could not take it: plain step below
+            folded = False
+            if fold:
+                folded = not dgr.fuse_pending()
+                if not folded:
+                    dgr.fuse_optimizer_into_next_backward(None)     # the rasterizer could not take it: plain step below
             with torch.no_grad():
                 # densification statistics are per-view: norm BEFORE any cross-rank reduction
                 self.model.add_densification_stats(vsp, vis, radii)                          # train.py:159-160
@@ -119,6 +122,8 @@ class Trainer:
             vis = vis_any | vis
         self.iteration += 1
         self.last = dict(loss=loss.detach(), image=image.detach(), radii=radii)
+        if len(views) == 1 and folded and self.densify is None:
+            return self.last            # parameters already updated by the backward; no gradient was stored, nothing to zero
         if self.world > 1 and self.optimizer_kind == "hip_sparse":
             # SparseGaussianAdam updates the rows visible in "the" view; with views sharded over ranks that is the UNION of
             # the ranks' visibility masks (a Gaussian seen by any rank has a non-zero averaged gradient) - otherwise the

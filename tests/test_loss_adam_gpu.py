@@ -162,7 +162,7 @@ def test_optimizer_step_folded_into_backward_is_bit_identical(kind):
 
 
 def test_split_dense_adam_culled_rows_on_side_stream_is_bit_identical():
-    """hip_fused splits the dense update: rows without tile instances on a side stream during the compositing kernels
+    """hip_fused can split the dense update (Trainer.split_rows): rows without tile instances on a side stream during the compositing kernels
     (gsr_adam_step_culled_rows, launched by the rasterizer's backward), rows with instances in the backward (gsr_backward_adam, sparse = 2).  Against the unsplit
     folded update (Trainer.split_rows off) on a scene where a good part of the Gaussians is off-screen."""
     import diff_gaussian_rasterization as dgr
@@ -182,7 +182,6 @@ def test_split_dense_adam_culled_rows_on_side_stream_is_bit_identical():
     for split in (False, True):
         model = GaussianModel.from_raw(scene(193).to("cuda"))
         tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True, optimizer="hip_fused")
-        assert tr.split_rows
         tr.split_rows = split
         culled = 0
         for it in range(6):
