@@ -50,6 +50,24 @@ int gsr_check(hipError_t e, const char* what) {
   return GSR_ERR_HIP;
 }
 
+static thread_local const char* t_fail_stage = nullptr;
+static thread_local hipError_t t_fail_err = hipSuccess;
+
+void gsr_note_launch_failure(const char* stage, hipError_t e) {
+  if (!t_fail_stage) { t_fail_stage = stage; t_fail_err = e; }
+}
+
+// status of the launches since the last call on this host thread: the first stage whose launch was rejected, if any
+int gsr_launch_status(const char* what) {
+  if (t_fail_stage) {
+    gsr_set_error("%s: launch of stage '%s' failed: %s", what, t_fail_stage, hipGetErrorString(t_fail_err));
+    t_fail_stage = nullptr;
+    t_fail_err = hipSuccess;
+    return GSR_ERR_HIP;
+  }
+  return gsr_check(hipGetLastError(), what);
+}
+
 static int debug_sync(const gsr_settings* s, hipStream_t st, const char* stage) {
   static const bool trace = getenv("GSR_TRACE") != nullptr;   // GSR_TRACE=1: name every stage on stderr as it completes
   if (trace) {
@@ -293,7 +311,7 @@ int gsr_forward_shade(const gsr_settings* s, const gsr_gaussians* g, void* geome
   const GsrGeomLayout L = gsr_geom_layout(g->P);
   gsr_launch_shade(s, g, (char*)geometry_state, L, (hipStream_t)stream);
   if ((rc = debug_sync(s, (hipStream_t)stream, "shade"))) return rc;
-  return gsr_check(hipGetLastError(), "shade launch");
+  return gsr_launch_status("shade");
 }
 
 // `num_rendered` sizes the binning state and the grids (the CAPACITY); the number of instances really present is read by the
@@ -359,7 +377,7 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
                         (const float4*)(geom + GL.rec), out_color, out_invdepth, (float*)(img + IL.final_T),
                         (uint32_t*)(img + IL.n_contrib), st);
   if ((rc = debug_sync(s, st, "render forward"))) return rc;
-  return gsr_check(hipGetLastError(), "forward launch");
+  return gsr_launch_status("forward");
 }
 
 int gsr_forward_render(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
@@ -461,7 +479,7 @@ static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const in
     return GSR_ERR_INVALID_ARGUMENT;
   }
   if ((rc = debug_sync(s, st, "preprocess backward"))) return rc;
-  return gsr_check(hipGetLastError(), "backward launch");
+  return gsr_launch_status("backward");
 }
 
 int gsr_backward(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,

@@ -176,11 +176,19 @@ void gsr_prof_begin(const char* name, hipStream_t st);
 void gsr_prof_end(hipStream_t st);
 extern int g_gsr_profile_on;
 
+// A launch that fails (bad configuration, too much LDS ...) is noted with ITS stage name right away (hipGetLastError does not
+// wait for the device); the entry point's final gsr_launch_status() then reports the first failing stage, not the last one.
+void gsr_note_launch_failure(const char* stage, hipError_t e);
+int gsr_launch_status(const char* what);
 #define GSR_LAUNCH(name, kern, grid, block, shmem, st, ...)                    \
   do {                                                                         \
     if (g_gsr_profile_on) gsr_prof_begin(name, st);                            \
     hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);             \
     if (g_gsr_profile_on) gsr_prof_end(st);                                    \
+    {                                                                          \
+      const hipError_t gsr_e_ = hipGetLastError();                             \
+      if (gsr_e_ != hipSuccess) gsr_note_launch_failure(name, gsr_e_);         \
+    }                                                                          \
   } while (0)
 
 // sort_scan.hip

@@ -49,11 +49,13 @@ _PLY_TYPES = {"float": "<f4", "float32": "<f4", "double": "<f8", "float64": "<f8
 
 
 def read_ply_vertices(path: str):
-    """-> dict name -> float64 array [P].  Binary little-endian and ascii PLY with scalar vertex properties."""
+    """-> dict name -> float64 array [P].  Binary little-endian and ascii PLY with scalar vertex properties.  Elements
+    declared BEFORE `vertex` (their data precedes the vertices in the body) are skipped when all their properties are scalars;
+    a list property there makes the offset of the vertex data unknowable without parsing it, which is refused."""
     with open(path, "rb") as f:
         if f.readline().strip() != b"ply":
             raise ValueError(f"{path}: not a PLY file")
-        fmt, count, props, in_vertex = None, 0, [], False
+        fmt, elements = None, []          # elements: [name, count, [(prop, dtype)], has_list]
         while True:
             line = f.readline()
             if not line:
@@ -64,19 +66,35 @@ def read_ply_vertices(path: str):
             if tok[0] == "format":
                 fmt = tok[1]
             elif tok[0] == "element":
-                in_vertex = tok[1] == "vertex"
-                if in_vertex:
-                    count = int(tok[2])
-            elif tok[0] == "property" and in_vertex:
+                elements.append([tok[1], int(tok[2]), [], False])
+            elif tok[0] == "property" and elements:
                 if tok[1] == "list":
-                    raise ValueError("list properties on vertices are not supported")
-                props.append((tok[2], _PLY_TYPES[tok[1]]))
+                    elements[-1][3] = True
+                else:
+                    if tok[1] not in _PLY_TYPES:
+                        raise ValueError(f"{path}: unknown property type {tok[1]}")
+                    elements[-1][2].append((tok[2], _PLY_TYPES[tok[1]]))
             elif tok[0] == "end_header":
                 break
+        names = [e[0] for e in elements]
+        if "vertex" not in names:
+            raise ValueError(f"{path}: no vertex element")
+        vi = names.index("vertex")
+        _, count, props, has_list = elements[vi]
+        if has_list:
+            raise ValueError("list properties on vertices are not supported")
+        for name, n, pr, lst in elements[:vi]:
+            if lst:
+                raise ValueError(f"{path}: element '{name}' with a list property precedes the vertices")
         if fmt == "binary_little_endian":
+            for name, n, pr, lst in elements[:vi]:
+                f.seek(n * np.dtype(pr).itemsize if pr else 0, 1)
             data = np.frombuffer(f.read(count * np.dtype(props).itemsize), dtype=np.dtype(props), count=count)
             return {n: data[n].astype(np.float64) for n, _ in props}
         if fmt == "ascii":
+            for name, n, pr, lst in elements[:vi]:
+                for _ in range(n):
+                    f.readline()
             arr = np.loadtxt(f, max_rows=count, ndmin=2)
             return {n: arr[:, i].astype(np.float64) for i, (n, _) in enumerate(props)}
         raise ValueError(f"{path}: unsupported PLY format {fmt}")

@@ -69,3 +69,37 @@ def test_checkpoint_capture_restore():
     s1 = m.optimizer.state[m._xyz]["exp_avg"]
     s2 = m2.optimizer.state[m2._xyz]["exp_avg"]
     assert torch.equal(s1, s2)
+
+
+def test_ply_reader_skips_elements_declared_before_vertex(tmp_path):
+    """A PLY whose header declares another element BEFORE `vertex` keeps that element's data in front of the vertices
+    (ADVICE r1: the reader used to take the bytes right after the header for vertices).  Hand-written files, both encodings;
+    a list property in front of the vertices is refused rather than mis-parsed."""
+    import numpy as np
+    from scene_utils import read_ply_vertices
+    verts = np.arange(12, dtype="<f4").reshape(4, 3) + 0.5
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement camera 2\nproperty float fx\nproperty uchar id\n"
+           "element vertex 4\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+    p = tmp_path / "pre.ply"
+    cam = np.zeros(2, dtype=[("fx", "<f4"), ("id", "u1")])
+    cam["fx"] = (7.0, 9.0)
+    with open(p, "wb") as f:
+        f.write(hdr.encode("ascii")); f.write(cam.tobytes()); f.write(verts.tobytes())
+    v = read_ply_vertices(str(p))
+    assert np.array_equal(np.stack((v["x"], v["y"], v["z"]), 1), verts.astype(np.float64))
+    pa = tmp_path / "pre_ascii.ply"
+    with open(pa, "w") as f:
+        f.write(hdr.replace("binary_little_endian", "ascii"))
+        f.write("7.0 1\n9.0 2\n")
+        for r in verts:
+            f.write(" ".join(str(float(x)) for x in r) + "\n")
+    v = read_ply_vertices(str(pa))
+    assert np.array_equal(np.stack((v["x"], v["y"], v["z"]), 1), verts.astype(np.float64))
+    pl = tmp_path / "list.ply"
+    with open(pl, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement face 1\nproperty list uchar int vertex_indices\n"
+                 "element vertex 1\nproperty float x\nend_header\n").encode("ascii"))
+        f.write(b"\x03" + np.zeros(3, "<i4").tobytes() + np.zeros(1, "<f4").tobytes())
+    import pytest
+    with pytest.raises(ValueError, match="precedes"):
+        read_ply_vertices(str(pl))
