@@ -61,7 +61,7 @@ extern "C" int gsr_gaussian_activations_forward(int32_t P, const float* raw_scal
   if (P == 0) return 0;
   GSR_LAUNCH("activations_fwd", k_activations_fwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P,
              raw_scaling, (const float4*)raw_rotation, raw_opacity, scaling, (float4*)rotation, opacity);
-  return gsr_check(hipGetLastError(), "activations forward");
+  return gsr_launch_status("activations forward");
 }
 
 extern "C" int gsr_gaussian_activations_backward(int32_t P, const float* raw_rotation, const float* scaling,
@@ -78,5 +78,5 @@ extern "C" int gsr_gaussian_activations_backward(int32_t P, const float* raw_rot
   GSR_LAUNCH("activations_bwd", k_activations_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P,
              (const float4*)raw_rotation, scaling, opacity, dL_dscaling, (const float4*)dL_drotation, dL_dopacity,
              dL_draw_scaling, (float4*)dL_draw_rotation, dL_draw_opacity);
-  return gsr_check(hipGetLastError(), "activations backward");
+  return gsr_launch_status("activations backward");
 }

@@ -114,7 +114,7 @@ int gsr_adam_step(int32_t count, float* const* params, const float* const* grads
   hipStream_t st = (hipStream_t)stream;
   GSR_LAUNCH("adam_dense", k_adam<false>, dim3(blocks), dim3(256), 0, st, b, (float)beta1, (float)beta2,
              (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (const uint8_t*)nullptr);
-  return gsr_check(hipGetLastError(), "adam launch");
+  return gsr_launch_status("adam launch");
 }
 
 // Sparse (visibility-masked) Adam: tensor i has N rows of numel[i]/N elements; rows with visible[row]==0 are untouched.
@@ -145,7 +145,7 @@ int gsr_sparse_adam_step(int32_t count, float* const* params, const float* const
   hipStream_t st = (hipStream_t)stream;
   GSR_LAUNCH("adam_sparse", k_adam<true>, dim3(blocks), dim3(256), 0, st, b, (float)beta1, (float)beta2,
              (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, visible);
-  return gsr_check(hipGetLastError(), "sparse adam launch");
+  return gsr_launch_status("sparse adam launch");
 }
 
 }  // extern "C"

@@ -515,7 +515,7 @@ int gsr_adam_step_culled_rows(const gsr_gaussians* g, const void* geometry_state
   if (rc) return rc;
   gsr_launch_adam_culled_rows(g->P, g->shs ? g->sh_coeffs : 0, (const char*)geometry_state, gsr_geom_layout(g->P), A,
                               (hipStream_t)stream);
-  return gsr_check(hipGetLastError(), "adam culled rows launch");
+  return gsr_launch_status("adam culled rows");
 }
 
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream) {
@@ -525,7 +525,7 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, u
   }
   if (P == 0) return 0;
   gsr_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
-  return gsr_check(hipGetLastError(), "mark_visible launch");
+  return gsr_launch_status("mark_visible");
 }
 
 int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float** rec48,
@@ -567,7 +567,7 @@ int gsr_debug_count_pairs(const gsr_settings* s, int32_t P, const void* geometry
   const char* bin = (const char*)binning_state;
   gsr_launch_count_pairs(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                          (const float4*)(geom + GL.rec), pairs, (hipStream_t)stream);
-  return gsr_check(hipGetLastError(), "count_pairs launch");
+  return gsr_launch_status("count_pairs");
 }
 
 int gsr_debug_image_views(const void* image_state, int32_t W, int32_t H, const float** final_T,

@@ -181,7 +181,7 @@ int gsr_densification_stats(int64_t P, const float* grad_means2D, const int32_t*
   if (P == 0) return 0;
   GSR_LAUNCH("densify_stats", k_densify_stats, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
              (int)P, grad_means2D, radii, xyz_gradient_accum, denom, max_radii2D);
-  return gsr_check(hipGetLastError(), "densification_stats launch");
+  return gsr_launch_status("densification_stats launch");
 }
 
 size_t gsr_densify_workspace_bytes(int64_t P) {
@@ -264,7 +264,7 @@ int gsr_densify_apply(int64_t P, const void* workspace, const float* const* in_p
              (const uint32_t*)ws, (const uint32_t*)(ws + a), (const uint32_t*)(ws + 2 * a), (const uint32_t*)(ws + 3 * a),
              (const uint32_t*)(ws + 4 * a), (const uint32_t*)(ws + 5 * a), (uint32_t)n_keep, (uint32_t)n_clone,
              (uint32_t)n_child, seed, source_of_row);
-  return gsr_check(hipGetLastError(), "densify_apply launch");
+  return gsr_launch_status("densify_apply launch");
 }
 
 }  // extern "C"

@@ -125,7 +125,7 @@ __global__ void k_debug_wave_reduce(const float* __restrict__ in, float* __restr
 
 extern "C" int gsr_debug_wave_reduce(const float* in640, float* out20, void* stream) {
   hipLaunchKernelGGL(k_debug_wave_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, in640, out20);
-  return gsr_check(hipGetLastError(), "debug wave reduce");
+  return gsr_launch_status("debug wave reduce");
 }
 
 #ifndef FWD_BATCH

@@ -275,7 +275,7 @@ int gsr_fused_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float
   dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   GSR_LAUNCH("ssim_fwd", k_ssim_fwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, C1, C2, win, img1, img2, ssim_map, dm_dmu1,
              dm_dsigma1_sq, dm_dsigma12, (float*)nullptr);
-  return gsr_check(hipGetLastError(), "ssim forward launch");
+  return gsr_launch_status("ssim forward launch");
 }
 
 // Fused training loss of reference train.py:114-121: (1-lambda) * mean|img1-img2| + lambda * (1 - mean(ssim_map)).
@@ -327,7 +327,7 @@ int gsr_fused_l1_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, fl
   const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
   GSR_LAUNCH("loss_finalize", k_loss_finalize, dim3(1), dim3(LOSS_FIN_THREADS), 0, st, (const float*)partials, nblk, lambda_dssim,
              inv_n, loss);
-  return gsr_check(hipGetLastError(), "fused loss forward launch");
+  return gsr_launch_status("fused loss forward launch");
 }
 
 // dL/dimg1 = upstream[0] * dloss/dimg1 (`upstream`: DEVICE scalar dL/dloss, or NULL for 1).
@@ -345,7 +345,7 @@ int gsr_fused_l1_ssim_backward(int32_t planes, int32_t H, int32_t W, float lambd
   GSR_LAUNCH("loss_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, win, img1, img2, (const float*)nullptr,
              -lambda_dssim * inv_n, (1.0f - lambda_dssim) * inv_n, upstream, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
              dL_dimg1);
-  return gsr_check(hipGetLastError(), "fused loss backward launch");
+  return gsr_launch_status("fused loss backward launch");
 }
 
 int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2,
@@ -362,7 +362,7 @@ int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* i
   dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   GSR_LAUNCH("ssim_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, win, img1, img2, dL_dmap, 0.f, 0.f,
              (const float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
-  return gsr_check(hipGetLastError(), "ssim backward launch");
+  return gsr_launch_status("ssim backward launch");
 }
 
 }  // extern "C"
