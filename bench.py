@@ -91,9 +91,13 @@ def _pmc(kernel, cfg_key):
         return None
     if doc.get("workload") != cfg_key:
         return None
-    for name, v in doc["kernels"].items():
-        if name.split("<")[0] == "k_" + kernel:
-            return v
+    # profile label -> kernel symbol(s): the backward has two forms, the folded optimizer step is a template instance
+    want = {"render_bwd": ("k_render_bwd_tile", "k_render_bwd"), "preprocess_bwd_adam": ("k_preprocess_bwd",),
+            "adam_dense": ("k_adam",), "adam_sparse": ("k_adam",), "radix_hist": ("k_radix_hist_all",)}.get(kernel, ("k_" + kernel,))
+    for sym in want:
+        for name, v in doc["kernels"].items():
+            if name.split("<")[0] == sym:
+                return v
     return None
 
 
@@ -121,6 +125,9 @@ def kernel_table(prof, R, N, P, M):
         "render_fwd": 44 * R + 24 * N,
         "render_bwd": 84 * R + 24 * N,
         "preprocess_bwd": P * (2 * b_in + 79) + 44 * R,
+        # optimizer folded in: no gradient stores (b_in), parameters read once (already counted), both moments read, parameters
+        # and both moments written: + 5 x (11 + 3 M) floats per Gaussian
+        "preprocess_bwd_adam": P * (b_in + 79) + 44 * R + 20 * (11 + 3 * M) * P,
         "emit_instances": 44 * P + 8 * R,          # order, offsets, 32-B binning record, slot_start; tile id + Gaussian id out
         "finalize_bins": 4 * R,                    # sorted tile ids in, 8 B per tile out
         "adam_dense": 28 * (11 + 3 * M) * P,       # param, grad, two moments in; param, two moments out
