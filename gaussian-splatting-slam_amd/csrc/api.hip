@@ -224,11 +224,27 @@ size_t gsr_backward_scratch_bytes(int32_t P, int64_t R) {
   return gsr_align((size_t)(R < 1 ? 1 : R) * 16 * GSR_IGRAD_F4);
 }
 
+// Optional: colour pass (SH -> RGB, the HBM-heavy half of the projection) on a library-owned side stream, concurrent with the
+// depth sort / scan / emission / tile sort, which are latency-bound and leave most of the machine idle (GSR_SHADE_STREAM=1).
+struct SideShade { hipStream_t stream; hipEvent_t fork, join; bool ok; };
+static SideShade* side_shade() {
+  static thread_local SideShade ss = {nullptr, nullptr, nullptr, false};
+  static thread_local bool tried = false;
+  if (!tried) {
+    tried = true;
+    ss.ok = hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+  }
+  return ss.ok ? &ss : nullptr;
+}
+
 // Geometry stages of the forward: projection, num_rendered (kept on the device in meta[2..3] and copied to `host_status`),
 // depth order, tile-count prefix sum.  Never waits for the device.
 static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
                             int32_t* radii, hipStream_t st, bool defer_color, uint32_t* host_status,
-                            hipEvent_t copied /* recorded right behind the status copy, or nullptr */) {
+                            hipEvent_t copied /* recorded right behind the status copy, or nullptr */,
+                            SideShade* shade_aside = nullptr) {
   const int P = g->P;
   const GsrGeomLayout L = gsr_geom_layout(P);
   if (!geometry_state || geometry_bytes < L.total) {
@@ -244,6 +260,12 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
 
   gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
+  if (shade_aside) {
+    if ((rc = gsr_check(hipEventRecord(shade_aside->fork, st), "fork shade"))) return rc;
+    if ((rc = gsr_check(hipStreamWaitEvent(shade_aside->stream, shade_aside->fork, 0), "fork shade"))) return rc;
+    gsr_launch_shade(s, g, geom, L, shade_aside->stream);
+    if ((rc = gsr_check(hipEventRecord(shade_aside->join, shade_aside->stream), "join shade"))) return rc;
+  }
 
   // num_rendered (meta[2..3]) and the error flags go back to the host NOW, ahead of the depth sort and the offset scan:
   // a blocking caller waits for the two words while the GPU still has work queued (no idle gap at the read-back), a
@@ -366,6 +388,9 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
     gsr_launch_finalize((uint32_t)R, n_dev, ks, bin, BL, st);
     if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
   }
+  if (!shade_late && sh_ready && g->P > 0) {   // colours were evaluated on a side stream: join it
+    if ((rc = gsr_check(hipStreamWaitEvent(st, sh_ready, 0), "join shade"))) return rc;
+  }
   if (shade_late && g->P > 0) {
     // the colours are the LAST thing the compositing needs: everything above ran without the SH coefficients, which may
     // still be receiving their update on another stream
@@ -403,9 +428,16 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
   if (rc) return rc;
   if (g->P > 0) {
     const bool late = defer_color != 0 && !g->colors_precomp;
-    if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late, host_status,
-                               nullptr)))
+    static const bool want_aside = getenv("GSR_SHADE_STREAM") && atoi(getenv("GSR_SHADE_STREAM")) != 0;
+    SideShade* aside = (want_aside && !late && !g->colors_precomp && !s->debug) ? side_shade() : nullptr;
+    if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late || aside != nullptr,
+                               host_status, nullptr, aside)))
       return rc;
+    if (aside) {
+      rc = forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
+                               out_color, out_invdepth, for_backward != 0, false, aside->join, stream);
+      return rc;
+    }
     return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
                                out_color, out_invdepth, for_backward != 0, late, (hipEvent_t)sh_ready_event, stream);
   }

@@ -178,3 +178,16 @@ def test_oracle_reproduces_committed_rasterizer_golden(aa):
     assert np.allclose(r["color"].numpy(), Gs[f"aa{aa}_color"], atol=1e-12)
     for k, v in r["grads"].items():
         assert np.allclose(v.numpy(), Gs[f"aa{aa}_grad_{k}"], atol=1e-9, rtol=1e-9), k
+
+
+@pytest.mark.parametrize("deg", [3, 4])
+def test_product_eval_sh_degree4_matches_reference(deg):
+    """scene_utils.sh.eval_sh (the convert_SHs_python branch of render()) at SH degree 4 - present only on the python path, in
+    the reference (utils/sh_utils.py:102-112) as here - against the reference's own eval_sh on 25-coefficient inputs
+    (tests/golden/reference_sh4.npz, generated by tests/golden/make_reference_fixtures_sh4.py)."""
+    import numpy as np
+    from scene_utils.sh import eval_sh
+    g4 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_sh4.npz"))
+    sh = torch.tensor(g4["sh_coeffs"]).transpose(1, 2)          # reference layout [P, 3, K]
+    out = eval_sh(deg, sh, torch.tensor(g4["dirs"]))
+    assert torch.allclose(out, torch.tensor(g4[f"sh_raw_deg{deg}"]), atol=1e-12, rtol=0)

@@ -484,3 +484,41 @@ def test_autograd_usage_patterns():
     c0, _, _ = call(rs[0], shs=sh_t.transpose(1, 2))
     c0.sum().backward()
     assert rel_l2(sh_t.grad.transpose(1, 2).cpu(), g0["shs"].cpu()) < 1e-6
+
+
+def test_python_sh_branch_at_degree_4():
+    """SH degree 4 exists only on the reference's python-SH branch (gaussian_renderer/__init__.py:74-79 with
+    --convert_SHs_python, utils/sh_utils.py:102-112; the native kernels stop at degree 3 upstream and here).  render() with
+    convert_SHs_python on a degree-4 model against the oracle fed the same precomputed colours, gradients into the 25
+    coefficients included."""
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import GaussianModel
+    from scene_utils.sh import eval_sh
+    from oracle import gs_oracle as O
+    raw = make_gaussians(1500, 4, seed=401, scale_factor=0.8)
+    assert raw.features_rest.shape[1] == 24
+    cam = fibonacci_cameras(2, 128, 80, seed=402)[1]
+    bg = torch.tensor([0.2, 0.1, 0.3])
+    # HIP path through render()
+    cam_d = fibonacci_cameras(2, 128, 80, seed=402, device="cuda")[1]
+    model = GaussianModel.from_raw(raw.to("cuda"))
+    assert model.active_sh_degree == 4
+    pkg = render(cam_d, model, PipelineParams(convert_SHs_python=True), bg.cuda())
+    gc, gd = upstream_grads(80, 128)
+    (pkg["render"] * gc.cuda()).sum().backward()
+    # oracle with the colours of the same formula in float64
+    act = raw.activated()
+    inp = {k: act[k].double().clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations")}
+    fdc = raw.features_dc.double().clone().requires_grad_(True)
+    frest = raw.features_rest.double().clone().requires_grad_(True)
+    shs = torch.cat((fdc, frest), 1)
+    d = inp["means3D"] - cam.camera_center.double()
+    col = torch.clamp_min(eval_sh(4, shs.transpose(1, 2), d / d.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+    s = settings_for(cam, 4, bg)
+    m2d = torch.zeros(1500, 3, dtype=torch.float64, requires_grad=True)
+    color, radii, invd = O.rasterize(inp["means3D"], m2d, inp["opacities"], s, colors_precomp=col, scales=inp["scales"],
+                                     rotations=inp["rotations"])
+    (color * gc.double()).sum().backward()
+    assert float((color.detach() - pkg["render"].detach().cpu().double()).abs().max()) < 2e-5
+    assert rel_l2(model._features_rest.grad.cpu(), frest.grad) < 1e-4 and rel_l2(model._features_dc.grad.cpu(), fdc.grad) < 1e-4
+    assert float(model._features_rest.grad[:, 15:].abs().max()) > 0          # the degree-4 band receives gradient
