@@ -477,6 +477,11 @@ static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const in
     gsr_set_error("backward: missing mandatory gradient buffers");
     return GSR_ERR_INVALID_ARGUMENT;
   }
+  if ((grads->xyz_gradient_accum != nullptr) != (grads->denom != nullptr) ||
+      (grads->denom != nullptr) != (grads->max_radii2D != nullptr)) {
+    gsr_set_error("backward: densification statistics need all three arrays (or none)");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
   if (g->P == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int W = s->image_width, H = s->image_height;

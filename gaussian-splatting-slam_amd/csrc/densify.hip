@@ -164,9 +164,7 @@ __global__ __launch_bounds__(256) void k_densify_stats(int P, const float* __res
   const int r = radii[i];
   if (r > 0) {
     const float gx = grad_means2D[3 * (size_t)i], gy = grad_means2D[3 * (size_t)i + 1];
-    accum[i] += sqrtf(gx * gx + gy * gy);
-    denom[i] += 1.0f;
-    max_radii[i] = fmaxf(max_radii[i], (float)r);
+    gsr_densify_stats_update(gx, gy, r, accum + i, denom + i, max_radii + i);
   }
 }
 

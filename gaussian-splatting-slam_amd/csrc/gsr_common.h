@@ -241,6 +241,15 @@ __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, const fl
   }
 }
 
+// add_densification_stats + max_radii2D of one Gaussian (reference scene/gaussian_model.py:431-433, train.py:159); shared by
+// k_densify_stats and the copy folded into k_preprocess_bwd, roundings spelled out so both give the same bits
+__device__ __forceinline__ void gsr_densify_stats_update(float gx, float gy, int radius, float* accum, float* denom,
+                                                         float* max_radii) {
+  *accum = __fadd_rn(*accum, __fsqrt_rn(__builtin_fmaf(gx, gx, __fmul_rn(gy, gy))));
+  *denom = __fadd_rn(*denom, 1.0f);
+  *max_radii = fmaxf(*max_radii, (float)radius);
+}
+
 // 16-B streaming (non-temporal) global accesses for data that passes through once
 typedef float gsr_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ gsr_f4 gsr_ld_stream(const float* p) {

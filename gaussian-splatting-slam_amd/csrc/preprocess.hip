@@ -554,7 +554,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     uint32_t cap, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_ddc, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
-    float* __restrict__ dL_dcov3D, const GsrAdamArgs A) {
+    float* __restrict__ dL_dcov3D, float* __restrict__ st_accum, float* __restrict__ st_denom,
+    float* __restrict__ st_max_radii, const GsrAdamArgs A) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
   __shared__ int32_t need_sh[256];
   const int S = 3 * sh_stride, Sp = S | 1;
@@ -828,6 +829,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     dL_dmeans2D[3 * (size_t)idx + 0] = g_m2d[0];
     dL_dmeans2D[3 * (size_t)idx + 1] = g_m2d[1];
     dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
+    if (st_accum) {     // this view's densification statistics, folded in (gsr_grads.xyz_gradient_accum / denom / max_radii2D)
+      const int rad = radii[idx];
+      if (rad > 0) gsr_densify_stats_update(g_m2d[0], g_m2d[1], rad, st_accum + idx, st_denom + idx, st_max_radii + idx);
+    }
   }
   if (ADAM) {
     // ---- optimizer step instead of gradient stores (raw-parameter call form: the gradients above ARE the leaves') ----
@@ -857,8 +862,36 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       float* Pg = A.p[2] + row0 * S;
       float* Mg = A.m[2] + row0 * S;
       float* Vg = A.v[2] + row0 * S;
+      if (ADAM == 1) {
+        // every piece is updated: the moments of the next TWO trips are in flight while this one is computed and stored (the
+        // loop is pure streaming - 32 B in, 48 B out per piece - and with two workgroups per CU it lives on loads in flight)
+        gsr_f4 mq[3], vq[3];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int iu = threadIdx.x + 256 * u;
+          if (iu < n4) { mq[u] = gsr_ld_stream(Mg + 4 * (size_t)iu); vq[u] = gsr_ld_stream(Vg + 4 * (size_t)iu); }
+        }
+        for (int i = threadIdx.x; i < n4; i += 256) {
+          if (i + 512 < n4) { mq[2] = gsr_ld_stream(Mg + 4 * (size_t)(i + 512)); vq[2] = gsr_ld_stream(Vg + 4 * (size_t)(i + 512)); }
+          float pp[4], mm[4] = {mq[0].x, mq[0].y, mq[0].z, mq[0].w}, vv[4] = {vq[0].x, vq[0].y, vq[0].z, vq[0].w};
+          int rr = r, cc = c;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            pp[k] = sh_lds[rr * Sp + cc];
+            const int kk = cc / 3, ch = cc - 3 * kk;
+            adam_elem<1>(pp[k], mm[k], vv[k], facs[rr * 19 + kk + 1] * facs[rr * 19 + 16 + ch], A, 2);
+            if (++cc == S) { cc = 0; rr++; }
+          }
+          gsr_st_stream(Pg + 4 * (size_t)i, gsr_f4{pp[0], pp[1], pp[2], pp[3]});
+          gsr_st_stream(Mg + 4 * (size_t)i, gsr_f4{mm[0], mm[1], mm[2], mm[3]});
+          gsr_st_stream(Vg + 4 * (size_t)i, gsr_f4{vv[0], vv[1], vv[2], vv[3]});
+          mq[0] = mq[1]; vq[0] = vq[1]; mq[1] = mq[2]; vq[1] = vq[2];
+          r += dr; c += dcol;
+          if (c >= S) { c -= S; r++; }
+        }
+      } else
       for (int i = threadIdx.x; i < n4; i += 256) {
-        if (ADAM != 1 && need_sh[r] <= 0 && need_sh[min(r + (c + 3 >= S ? 1 : 0), rows - 1)] <= 0) {
+        if (need_sh[r] <= 0 && need_sh[min(r + (c + 3 >= S ? 1 : 0), rows - 1)] <= 0) {
           r += dr; c += dcol;                   // a piece of invisible rows only: neither read nor written
           if (c >= S) { c -= S; r++; }
           continue;
@@ -1113,7 +1146,7 @@ int gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, con
       (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), igrad,                       \
       (const uint32_t*)(geom + L.meta) + 2, cap, gr->dL_dmeans3D,                                                      \
       gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities, gr->dL_dscales, gr->dL_drotations, \
-      gr->dL_dcov3D, A
+      gr->dL_dcov3D, gr->xyz_gradient_accum, gr->denom, gr->max_radii2D, A
 #define GSR_PRE_BWD(ST, AD)                                                                                            \
   do {                                                                                                                 \
     if (lds > 48 * 1024)                                                                                               \

@@ -42,6 +42,7 @@ class gsr_grads(C.Structure):
         ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_ddc", C.c_void_p), ("dL_dshs", C.c_void_p),
         ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
         ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+        ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p),
     ]
 
 

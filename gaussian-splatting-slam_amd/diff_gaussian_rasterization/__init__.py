@@ -57,6 +57,19 @@ fused_backward_count = 0
 
 _split_rows = False
 _side_streams = {}
+_fold_stats = None
+
+
+def fold_densification_stats_into_next_backward(xyz_gradient_accum, denom, max_radii2D):
+    """One-shot: the next rasterizer backward also performs this view's `add_densification_stats` (reference
+    scene/gaussian_model.py:431-433) and the `max_radii2D` update (train.py:159) on the given [P,1], [P,1], [P] tensors - same
+    arithmetic as gsr_densification_stats, no extra pass and no extra launch.  None cancels."""
+    global _fold_stats
+    _fold_stats = None if xyz_gradient_accum is None else (xyz_gradient_accum, denom, max_radii2D)
+
+
+def stats_pending():
+    return _fold_stats is not None
 
 
 def fuse_optimizer_into_next_backward(optimizer, split_rows=False):
@@ -308,9 +321,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                   ctx.raw_activations)
                 scratch = ws.ensure_scratch(lib, P, R)
+                global _fused_optimizer, fused_backward_count, _fold_stats
+                stats, _fold_stats = _fold_stats, None
+                if stats is not None and (stats[0].shape[0] != P or not all(t.is_contiguous() and t.dtype == torch.float32
+                                                                            for t in stats)):
+                    raise _C.GsrError("fold_densification_stats: statistics tensors do not match this forward's Gaussians")
                 gr = _C.gsr_grads(*[None if t is None else t.data_ptr() for t in
-                                    (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov)])
-                global _fused_optimizer, fused_backward_count
+                                    (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov) +
+                                    (stats if stats is not None else (None, None, None))])
                 fused = None
                 if _fused_optimizer is not None and ctx.raw_activations and dc is not None and colors_precomp is None:
                     split = _split_rows and not isinstance(_fused_optimizer, SparseGaussianAdam)

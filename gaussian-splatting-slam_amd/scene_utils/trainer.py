@@ -102,6 +102,13 @@ class Trainer:
                 loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[v]).mean()
             if len(views) > 1:
                 loss = loss / len(views)
+            # this view's densification statistics ride in the rasterizer's backward (one pass and one launch less); any
+            # renderer that does not take the hand-off (the CPU oracle in the gloo tests) leaves it pending -> plain call below
+            fold_stats = self.model.get_xyz.is_cuda
+            if fold_stats:
+                import diff_gaussian_rasterization as dgr
+                dgr.fold_densification_stats_into_next_backward(self.model.xyz_gradient_accum, self.model.denom,
+                                                                self.model.max_radii2D)
             fold = self.fuse_step and self.world == 1 and len(views) == 1 and not self._densify_due(self.iteration + 1) \
                 and self.separate_sh
             if fold:
@@ -113,9 +120,13 @@ class Trainer:
                 folded = not dgr.fuse_pending()
                 if not folded:
                     dgr.fuse_optimizer_into_next_backward(None)     # the rasterizer could not take it: plain step below
-            with torch.no_grad():
-                # densification statistics are per-view: norm BEFORE any cross-rank reduction
-                self.model.add_densification_stats(vsp, vis, radii)                          # train.py:159-160
+            if fold_stats and dgr.stats_pending():
+                dgr.fold_densification_stats_into_next_backward(None, None, None)
+                fold_stats = False
+            if not fold_stats:
+                with torch.no_grad():
+                    # densification statistics are per-view: norm BEFORE any cross-rank reduction
+                    self.model.add_densification_stats(vsp, vis, radii)                      # train.py:159-160
             if n + 1 < len(views):
                 vis_any = vis if n == 0 else (vis_any | vis)
         if len(views) > 1:

@@ -93,6 +93,13 @@ typedef struct gsr_grads {
   float* dL_dscales;    /* [P,3] or NULL */
   float* dL_drotations; /* [P,4] or NULL */
   float* dL_dcov3D;     /* [P,6] or NULL (cov3D_precomp) */
+  /* Optional (all three or none): the backward also performs this view's add_densification_stats (reference
+   * scene/gaussian_model.py:431-433) and max_radii2D update (train.py:159) - where radii > 0: xyz_gradient_accum +=
+   * |dL_dmeans2D.xy|, denom += 1, max_radii2D = max(max_radii2D, radii) - the same arithmetic as gsr_densification_stats,
+   * without the extra pass over P. */
+  float* xyz_gradient_accum; /* [P,1] */
+  float* denom;              /* [P,1] */
+  float* max_radii2D;        /* [P]   */
 } gsr_grads;
 
 int gsr_abi_version(void);

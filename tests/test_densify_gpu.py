@@ -148,3 +148,33 @@ def test_densification_stats_kernel_matches_reference_lines():
     mr0[vis] = torch.max(mr0[vis], radii[vis].float())                          # train.py:159
     assert torch.allclose(m.xyz_gradient_accum, acc0, rtol=1e-6, atol=1e-7)
     assert torch.equal(m.denom, den0) and torch.equal(m.max_radii2D, mr0)
+
+
+def test_densification_stats_folded_into_backward_match_the_separate_kernel():
+    """gsr_grads.xyz_gradient_accum / denom / max_radii2D: the rasterizer's backward updating the statistics itself against
+    the separate pass (k_densify_stats on viewspace_points.grad), bit for bit, over three views (accumulation included)."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import fibonacci_cameras
+    cams = fibonacci_cameras(3, 160, 96, seed=77, device="cuda")
+    bg = torch.zeros(3, device="cuda")
+    res = {}
+    for folded in (False, True):
+        m = GaussianModel.from_raw(make_gaussians(4000, 2, seed=78, scale_factor=0.7).to("cuda"))
+        m.training_setup(optimizer="hip")
+        for i, cam in enumerate(cams):
+            pkg = render(cam, m, PipelineParams(), bg, separate_sh=True)
+            if folded:
+                dgr.fold_densification_stats_into_next_backward(m.xyz_gradient_accum, m.denom, m.max_radii2D)
+            (pkg["render"] * (1.0 + i)).sum().backward()
+            if folded:
+                assert not dgr.stats_pending()
+            else:
+                m.add_densification_stats(pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
+            for p in m.parameters():
+                p.grad = None
+        torch.cuda.synchronize()
+        res[folded] = (m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone())
+    assert float(res[True][1].sum()) > 1000
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
