@@ -303,16 +303,29 @@ class _RasterizeGaussians(torch.autograd.Function):
         def like(t, *shape):
             return torch.empty(*shape, dtype=torch.float32, device=dev) if t is not None else None
 
+        global _fused_optimizer, fused_backward_count, _fold_stats
         with _C.on_device(dev):
-            d_means3D = torch.empty(P, 3, dtype=torch.float32, device=dev)
+            stats, _fold_stats = _fold_stats, None
+            if stats is not None and (stats[0].shape[0] != P or not all(t.is_contiguous() and t.dtype == torch.float32
+                                                                        for t in stats)):
+                raise _C.GsrError("fold_densification_stats: statistics tensors do not match this forward's Gaussians")
+            fused, split = None, False
+            if P > 0 and _fused_optimizer is not None and ctx.raw_activations and dc is not None and colors_precomp is None:
+                split = _split_rows and not isinstance(_fused_optimizer, SparseGaussianAdam)
+                fused = _fused_adam_struct(_fused_optimizer, (means3D, dc, sh, opacities, scales, rotations),
+                                           rows="with_instances" if split else None)
             d_means2D = torch.empty(P, 3, dtype=torch.float32, device=dev)
-            d_opac = torch.empty(opacities.shape if opacities is not None else (P, 1), dtype=torch.float32, device=dev)
-            d_dc = like(dc, *(dc.shape if dc is not None else ()))
-            d_sh = like(sh, *(sh.shape if sh is not None else ()))
-            d_col = like(colors_precomp, P, 3)
-            d_scales = like(scales, P, 3)
-            d_rot = like(rotations, P, 4)
-            d_cov = like(cov3D_precomp, P, 6)
+            if fused is None:
+                d_means3D = torch.empty(P, 3, dtype=torch.float32, device=dev)
+                d_opac = torch.empty(opacities.shape if opacities is not None else (P, 1), dtype=torch.float32, device=dev)
+                d_dc = like(dc, *(dc.shape if dc is not None else ()))
+                d_sh = like(sh, *(sh.shape if sh is not None else ()))
+                d_col = like(colors_precomp, P, 3)
+                d_scales = like(scales, P, 3)
+                d_rot = like(rotations, P, 4)
+                d_cov = like(cov3D_precomp, P, 6)
+            else:       # the optimizer step rides in the backward: no gradient but the screen-space one is materialised
+                d_means3D = d_opac = d_dc = d_sh = d_col = d_scales = d_rot = d_cov = None
             if P > 0:
                 cur = _C.raw_stream()
                 if ws.stream is not None and ws.stream != cur:
@@ -321,22 +334,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g = _gauss_struct(P, means3D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                   ctx.raw_activations)
                 scratch = ws.ensure_scratch(lib, P, R)
-                global _fused_optimizer, fused_backward_count, _fold_stats
-                stats, _fold_stats = _fold_stats, None
-                if stats is not None and (stats[0].shape[0] != P or not all(t.is_contiguous() and t.dtype == torch.float32
-                                                                            for t in stats)):
-                    raise _C.GsrError("fold_densification_stats: statistics tensors do not match this forward's Gaussians")
                 gr = _C.gsr_grads(*[None if t is None else t.data_ptr() for t in
                                     (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov) +
                                     (stats if stats is not None else (None, None, None))])
-                fused = None
-                if _fused_optimizer is not None and ctx.raw_activations and dc is not None and colors_precomp is None:
-                    split = _split_rows and not isinstance(_fused_optimizer, SparseGaussianAdam)
-                    fused = _fused_adam_struct(_fused_optimizer, (means3D, dc, sh, opacities, scales, rotations),
-                                               rows="with_instances" if split else None)
                 try:
                     if fused is not None:
-                        # the optimizer step rides in the backward's last kernel: no gradient leaves the device registers
                         _fused_optimizer = None
                         fused_backward_count += 1
                         if split:
@@ -354,11 +356,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                        C.byref(fused[0]), _stream()))
                         if split:
                             torch.cuda.current_stream().wait_stream(side)   # what follows here sees both halves of the update
-                        ws.stream = cur
-                        return (None, d_means2D, None, None, None, None, None, None, None, None, None, None)
-                    _C.check(lib.gsr_backward(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom), _C.ptr(binning),
-                                              _C.ptr(img), R, _C.ptr(grad_color), _C.ptr(grad_invdepth),
-                                              _C.ptr(scratch), scratch.numel(), C.byref(gr), _stream()))
+                    else:
+                        _C.check(lib.gsr_backward(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom), _C.ptr(binning),
+                                                  _C.ptr(img), R, _C.ptr(grad_color), _C.ptr(grad_invdepth),
+                                                  _C.ptr(scratch), scratch.numel(), C.byref(gr), _stream()))
                 except _C.GsrError:
                     if rs.debug:
                         _dump("snapshot_bw.dump", rs, means3D, dc, sh, colors_precomp, opacities, scales, rotations,
