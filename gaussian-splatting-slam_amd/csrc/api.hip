@@ -607,6 +607,20 @@ int gsr_debug_count_pairs(const gsr_settings* s, int32_t P, const void* geometry
   return gsr_launch_status("count_pairs");
 }
 
+size_t gsr_debug_radix_tmp_bytes(int64_t n) { return gsr_align(gsr_radix_tmp_elems((size_t)(n < 1 ? 1 : n)) * 4); }
+
+int gsr_debug_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* w0, uint32_t* w1, int64_t n,
+                         int32_t bits, int32_t vals_iota, const uint32_t* n_dev, void* tmp, void* stream) {
+  if (n < 0 || n > 0x3FFFFFFF || bits < 1 || bits > 32 || !k0 || !v0 || !k1 || !v1 || !tmp || (w0 == nullptr) != (w1 == nullptr)) {
+    gsr_set_error("debug_radix_sort: bad arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  const int where = gsr_radix_sort_pairs(k0, v0, k1, v1, vals_iota != 0, (size_t)n, bits, (uint32_t*)tmp, (hipStream_t)stream,
+                                         w0, w1, n_dev, false);
+  const int rc = gsr_launch_status("debug radix sort");
+  return rc ? rc : where;
+}
+
 int gsr_debug_image_views(const void* image_state, int32_t W, int32_t H, const float** final_T,
                           const uint32_t** n_contrib) {
   const GsrImgLayout IL = gsr_img_layout((size_t)W * H);

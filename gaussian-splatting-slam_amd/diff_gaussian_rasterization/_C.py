@@ -89,6 +89,8 @@ EXPORTS = {
                                           C.POINTER(C.c_void_p)]),
     "gsr_debug_count_pairs": (C.c_int, [C.POINTER(gsr_settings), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                         C.c_void_p]),
+    "gsr_debug_radix_tmp_bytes": (C.c_size_t, [C.c_int64]),
+    "gsr_debug_radix_sort": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_image_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p)]),
     "gsr_fused_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),

@@ -224,6 +224,13 @@ int gsr_debug_binning_views(const void* binning_state, int32_t image_width, int3
  * state buffers of a finished forward.  (The backward's count is the sum of n_contrib: it replays entries 1..n_contrib.) */
 int gsr_debug_count_pairs(const gsr_settings* s, int32_t P, const void* geometry_state, const void* binning_state,
                           int64_t num_rendered, uint32_t* pairs, void* stream);
+/* test / measurement hook: the library's stable LSD radix sort (sort_scan.hip) on caller-provided ping-pong buffers: keys k0
+ * (input) / k1, values v0 / v1 (vals_iota != 0: value = index, v0 is not read), optional second payload w0 / w1 (both or
+ * neither), key bits [0, bits); n_dev: optional device pointer to a 64-bit count (the kernels then sort min(*n_dev, n) keys).
+ * tmp: gsr_debug_radix_tmp_bytes(n) bytes.  Returns 0 / 1 = the buffer set holding the result, or an error code. */
+size_t gsr_debug_radix_tmp_bytes(int64_t n);
+int gsr_debug_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t* w0, uint32_t* w1, int64_t n,
+                         int32_t bits, int32_t vals_iota, const uint32_t* n_dev, void* tmp, void* stream);
 int gsr_debug_image_views(const void* image_state, int32_t image_width, int32_t image_height,
                           const float** final_T, const uint32_t** n_contrib);
 

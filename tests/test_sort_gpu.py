@@ -1,0 +1,63 @@
+"""The library's stable LSD radix sort (one kernel per pass: ticketed chunks + decoupled look-back, sort_scan.hip) through the
+C ABI test hook, bit-exact against numpy's stable argsort: sizes around the chunk boundaries, every pass count, the dual
+payload, a device-side count smaller than the capacity, a uniform digit (identity-pass shortcut), heavy duplicates."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sort(keys, bits, dual=False, n_dev=None, vals=None):
+    from diff_gaussian_rasterization import _C
+    lib = _C.lib()
+    n = keys.numel()
+    dev = "cuda"
+    k0 = keys.to(dev).contiguous()
+    k1 = torch.empty_like(k0)
+    v0 = torch.empty(n, dtype=torch.int32, device=dev) if vals is None else vals.to(dev).contiguous()
+    v1 = torch.empty(n, dtype=torch.int32, device=dev)
+    w0 = (torch.arange(n, dtype=torch.int32, device=dev) * 7 + 3) if dual else None
+    w1 = torch.empty(n, dtype=torch.int32, device=dev) if dual else None
+    tmp = torch.empty(lib.gsr_debug_radix_tmp_bytes(n), dtype=torch.uint8, device=dev)
+    nd = None
+    if n_dev is not None:
+        nd = torch.tensor([n_dev, 0], dtype=torch.int32, device=dev)
+    where = _C.check(lib.gsr_debug_radix_sort(_C.ptr(k0), _C.ptr(v0), _C.ptr(k1), _C.ptr(v1), _C.ptr(w0), _C.ptr(w1), n, bits,
+                                              1 if vals is None else 0, _C.ptr(nd), _C.ptr(tmp), _C._stream()))
+    torch.cuda.synchronize()
+    ks, vs, ws = (k1, v1, w1) if where else (k0, v0, w0)
+    return ks.cpu().numpy().view(np.uint32), vs.cpu().numpy().view(np.uint32), None if ws is None else ws.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 32), (63, 8), (2047, 13), (2048, 13), (2049, 16), (4096, 32), (40_001, 24),
+                                    (300_000, 32), (2_200_000, 13), (3_000_001, 15)])
+def test_radix_sort_matches_numpy_stable_sort(n, bits):
+    rng = np.random.default_rng(n + bits)
+    kn = rng.integers(0, 1 << bits, n, dtype=np.uint64).astype(np.uint32)
+    keys = torch.from_numpy(kn.view(np.int32).copy())
+    order = np.argsort(kn, kind="stable")
+    ks, vs, ws = _sort(keys, bits, dual=(n % 2 == 1))
+    assert (ks == kn[order]).all() and (vs == order.astype(np.uint32)).all()
+    if ws is not None:
+        assert (ws == (order.astype(np.uint32) * 7 + 3)).all()
+
+
+def test_radix_sort_duplicates_uniform_digit_and_device_count():
+    gen = torch.Generator().manual_seed(5)
+    n = 123_457
+    # (a) every key has the same top byte (identity-pass shortcut) and few distinct values overall
+    keys = (torch.randint(0, 37, (n,), generator=gen, dtype=torch.int64) * 4099 + 0x40000000).to(torch.int32)
+    kn = keys.numpy().view(np.uint32)
+    order = np.argsort(kn, kind="stable")
+    ks, vs, _ = _sort(keys, 32)
+    assert (ks == kn[order]).all() and (vs == order.astype(np.uint32)).all()
+    # (b) given values instead of the index, and a device-side count below the capacity: only the first m keys are sorted
+    vals = torch.randint(0, 2**31 - 1, (n,), generator=gen, dtype=torch.int64).to(torch.int32)
+    m = 77_777
+    ks, vs, ws = _sort(keys, 32, dual=True, n_dev=m, vals=vals)
+    order_m = np.argsort(kn[:m], kind="stable")
+    assert (ks[:m] == kn[:m][order_m]).all() and (vs[:m] == vals.numpy().view(np.uint32)[:m][order_m]).all()
+    assert (ws[:m] == (order_m.astype(np.uint32) * 7 + 3)).all()
