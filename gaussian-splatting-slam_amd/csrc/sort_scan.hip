@@ -239,7 +239,11 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
       return;
     }
   }
+#ifdef GSR_EXP_NOTICKET   // (timing experiment only)
+  if (tid == 0) s_chunk = blockIdx.x;
+#else
   if (tid == 0) s_chunk = atomicAdd(ticket, 1u);    // chunks are taken in ticket order: every predecessor is already running
+#endif
 #pragma unroll
   for (int i = 0; i < 4; i++) wave_run[i][tid] = 0;
   __syncthreads();
@@ -317,7 +321,11 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
   // workgroup holds an earlier ticket, i.e. is resident or finished: the wait is bounded by that workgroup's phase 1.
   {
     uint32_t excl = 0;
+#ifdef GSR_EXP_NOLB         // (timing experiment only: wrong bases, every store still inside [0, n))
+    if (false) {
+#else
     if (chunk != 0) {
+#endif
       // GSR_LB_WINDOW predecessors per trip, all loads in flight together: with ~1000 chunks started at once the walk back
       // to the nearest finished prefix is tens of chunks long, and one dependent ~1 us poll per chunk made the pass slower
       // than the three-kernel form it replaces
