@@ -302,7 +302,9 @@ int gsr_gaussian_activations_backward(int32_t P, const float* raw_rotation, cons
                                       float* dL_draw_scaling, float* dL_draw_rotation, float* dL_draw_opacity,
                                       void* stream);
 
-/* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline block). */
+/* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline block).  A measurement aid, process-
+ * global and meant for ONE host thread driving the library at a time: enabling it while several host threads launch
+ * concurrently attributes times correctly per thread (the open event pair is thread-local) but adds a lock to every launch. */
 void gsr_profile_enable(int32_t on);
 void gsr_profile_reset(void);
 /* Fills up to `max` entries; returns the number of distinct kernels.  `names` receives pointers to
