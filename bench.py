@@ -89,7 +89,11 @@ def _pmc(kernel, cfg_key):
         doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
     except Exception:
         return None
-    if doc.get("workload") != cfg_key:
+    if "workloads" in doc:
+        doc = doc["workloads"].get(cfg_key)
+        if doc is None:
+            return None
+    elif doc.get("workload") != cfg_key:
         return None
     # profile label -> kernel symbol(s): the backward has two forms, the folded optimizer step is a template instance
     want = {"render_bwd": ("k_render_bwd_tile", "k_render_bwd"), "preprocess_bwd_adam": ("k_preprocess_bwd",),

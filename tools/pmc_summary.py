@@ -49,7 +49,17 @@ def main():
         w.writeheader()
         for r in rows:
             w.writerow({f: r.get(f, "") for f in fields})
-    json.dump({"source": name + ".csv", "workload": workload, "kernels": latest}, open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1)
+    # pmc_latest.json holds one entry per workload; bench.py picks the one matching its own run
+    path = os.path.join(root, "profiles", "pmc_latest.json")
+    try:
+        doc = json.load(open(path))
+        if "workloads" not in doc:
+            doc = {"workloads": {doc["workload"]: {"source": doc["source"], "kernels": doc["kernels"]}}} if "workload" in doc \
+                else {"workloads": {}}
+    except Exception:
+        doc = {"workloads": {}}
+    doc["workloads"][workload] = {"source": name + ".csv", "kernels": latest}
+    json.dump(doc, open(path, "w"), indent=1)
     print("wrote", name + ".csv", "and pmc_latest.json for", len(rows), "kernels")
 
 
