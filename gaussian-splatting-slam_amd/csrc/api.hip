@@ -224,8 +224,10 @@ size_t gsr_backward_scratch_bytes(int32_t P, int64_t R) {
   return gsr_align((size_t)(R < 1 ? 1 : R) * 16 * GSR_IGRAD_F4);
 }
 
-// Optional: colour pass (SH -> RGB, the HBM-heavy half of the projection) on a library-owned side stream, concurrent with the
-// depth sort / scan / emission / tile sort, which are latency-bound and leave most of the machine idle (GSR_SHADE_STREAM=1).
+// Colour pass (SH -> RGB, the HBM-heavy half of the projection) on a library-owned side stream, concurrent with the depth sort /
+// scan / emission / tile sort, which are latency-bound and leave most of the machine idle.  Used by gsr_forward_async from
+// 200 k Gaussians up (below that the extra launch and two event operations cost the host more than the overlap saves);
+// GSR_SHADE_STREAM=0 keeps everything on the caller's stream, =1 forces the side stream at any size.  Same results.
 struct SideShade { hipStream_t stream; hipEvent_t fork, join; bool ok; };
 static SideShade* side_shade() {
   static thread_local SideShade ss = {nullptr, nullptr, nullptr, false};
@@ -428,8 +430,9 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
   if (rc) return rc;
   if (g->P > 0) {
     const bool late = defer_color != 0 && !g->colors_precomp;
-    static const bool want_aside = getenv("GSR_SHADE_STREAM") && atoi(getenv("GSR_SHADE_STREAM")) != 0;
-    SideShade* aside = (want_aside && !late && !g->colors_precomp && !s->debug) ? side_shade() : nullptr;
+    static const int aside_env = getenv("GSR_SHADE_STREAM") ? atoi(getenv("GSR_SHADE_STREAM")) : -1;
+    const bool want_aside = aside_env < 0 ? g->P >= 200000 : aside_env != 0;
+    SideShade* aside = (want_aside && !late && !g->colors_precomp && (g->shs || g->dc) && !s->debug) ? side_shade() : nullptr;
     if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late || aside != nullptr,
                                host_status, nullptr, aside)))
       return rc;
