@@ -249,6 +249,11 @@ def main():
     ap.add_argument("--densify", action="store_true",
                     help="run the reference densify/prune schedule (train.py:155-168) inside the timed loop (config 5)")
     ap.add_argument("--densify-from", type=int, default=500)
+    ap.add_argument("--densify-grad-threshold", type=float, default=0.0002,
+                    help="densify_grad_threshold (reference arguments/__init__.py:90: 0.0002); the synthetic C5 scene needs a "
+                         "lower one to grow the way a real capture does")
+    ap.add_argument("--densify-max", type=int, default=None,
+                    help="stop densifying once the model has this many Gaussians (C5: 500000)")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views per rank per optimizer step (gradient accumulation; default 1 = the reference's batch-1 step). "
                          "Amortises the N>1 gradient exchange and Adam over k views; value still counts view-iterations")
@@ -317,7 +322,8 @@ def main():
     trainer.split_rows = bool(args.split_rows)
     if args.densify:
         # cameras_extent of the reference = 1.1 x radius of the camera centres (scene/dataset_readers.py getNerfppNorm)
-        trainer.enable_densification(extent=1.1 * 4.0, from_iter=args.densify_from)
+        trainer.enable_densification(extent=1.1 * 4.0, from_iter=args.densify_from,
+                                     grad_threshold=args.densify_grad_threshold, max_gaussians=args.densify_max)
     P = cfg["P"]
     M = (cfg["deg"] + 1) ** 2
     W, H = cfg["W"], cfg["H"]
@@ -385,6 +391,8 @@ def main():
                                f"{W}x{H}, {len(cams)} views, one view per rank per step, all-reduce of "
                                f"{59 if cfg['deg'] == 3 else 11 + 3 * M}-float/Gaussian grads when N>1",
                    "gaussians": P, "gaussians_final": int(model.get_xyz.shape[0]), "densify": bool(args.densify),
+                   "densify_grad_threshold": args.densify_grad_threshold if args.densify else None,
+                   "densify_max": args.densify_max if args.densify else None,
                    "sh_degree": cfg["deg"], "width": W, "height": H, "views": len(cams),
                    "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}",
                    "views_per_rank_per_step": k, "overlap_comm": bool(trainer.overlap_comm), "exchange": trainer.exchange,

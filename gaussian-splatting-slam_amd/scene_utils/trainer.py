@@ -84,10 +84,12 @@ class Trainer:
         return self.model.max_radii2D
 
     def enable_densification(self, extent, from_iter=500, until_iter=15000, interval=100, opacity_reset_interval=3000,
-                             grad_threshold=0.0002, min_opacity=0.005, seed=0):
-        """Schedule and thresholds of reference train.py:155-168 / arguments/__init__.py:84-90."""
+                             grad_threshold=0.0002, min_opacity=0.005, seed=0, max_gaussians=None):
+        """Schedule and thresholds of reference train.py:155-168 / arguments/__init__.py:84-90.  `max_gaussians` (not in the
+        reference; for the synthetic growth benchmark): no further densification once the model has that many rows."""
         self.densify = dict(extent=extent, from_iter=from_iter, until_iter=until_iter, interval=interval,
-                            reset=opacity_reset_interval, thr=grad_threshold, min_opacity=min_opacity, seed=seed)
+                            reset=opacity_reset_interval, thr=grad_threshold, min_opacity=min_opacity, seed=seed,
+                            max_gaussians=max_gaussians)
 
     def step(self, view_idx):
         """One optimizer step.  `view_idx`: one view (the reference's batch-1 step) or a list of views whose gradients are
@@ -169,7 +171,12 @@ class Trainer:
         d, it = self.densify, (self.iteration if it is None else it)
         if d is None or it >= d["until_iter"]:
             return False
-        return (it > d["from_iter"] and it % d["interval"] == 0) or it % d["reset"] == 0
+        grow = it > d["from_iter"] and it % d["interval"] == 0 and not self._at_capacity()
+        return grow or it % d["reset"] == 0
+
+    def _at_capacity(self):
+        m = self.densify.get("max_gaussians") if self.densify else None
+        return m is not None and int(self.model.get_xyz.shape[0]) >= m
 
     @torch.no_grad()
     def _exchange_and_step_overlapped(self, vis, radii):
@@ -219,7 +226,7 @@ class Trainer:
         if it >= d["until_iter"]:
             return
         changed = False
-        if it > d["from_iter"] and it % d["interval"] == 0:
+        if it > d["from_iter"] and it % d["interval"] == 0 and not self._at_capacity():
             # per-view statistics -> identical on all ranks, so every rank takes the same decisions
             reduce_densification_stats(self.model.xyz_gradient_accum, self.model.denom, self.model.max_radii2D, self.world)
             size_threshold = 20 if it > d["reset"] else None
