@@ -353,6 +353,7 @@ def main():
     log("warmup done")
     alloc0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    stats_before = dict(dgr.call_stats(device, wait=False))
     host_ms = []
     t0 = time.perf_counter()
     marks[0].record()
@@ -384,8 +385,12 @@ def main():
         "ms_per_step_median": pct(step_ms, 0.5), "ms_per_step_p10": pct(step_ms, 0.1), "ms_per_step_p90": pct(step_ms, 0.9),
         "host_ms_per_step_median": pct(host_ms, 0.5), "host_ms_per_step_p90": pct(host_ms, 0.9),
         "device_allocs_in_timed_region": int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - alloc0),
+        # frames of the whole run (warm-up included) by forward form; tile_local_frames_timed of the K*views timed frames
         "forward_mode": {"mode": dgr.forward_mode(), "async_frames": timed_stats["async_frames"],
-                         "sync_frames": timed_stats["sync_frames"], "overflow_frames": timed_stats["overflow_frames"]},
+                         "sync_frames": timed_stats["sync_frames"], "overflow_frames": timed_stats["overflow_frames"],
+                         "tile_local_frames": timed_stats.get("tile_local_frames", 0),
+                         "tile_local_frames_timed": timed_stats.get("tile_local_frames", 0)
+                                                    - stats_before.get("tile_local_frames", 0)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {P} Gaussians, SH degree {cfg['deg']}, "
                                f"{W}x{H}, {len(cams)} views, one view per rank per step, all-reduce of "

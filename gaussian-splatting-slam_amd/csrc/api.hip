@@ -21,7 +21,9 @@ int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const i
                               const GsrGeomLayout&, const float4*, uint32_t, const gsr_grads*, const GsrAdamArgs*, int,
                               hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
-void gsr_launch_emit(int, int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, hipStream_t);
+void gsr_launch_emit(int, int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, bool, hipStream_t);
+void gsr_launch_tile_depth_sort(int, bool, const uint2*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*,
+                                uint32_t*, hipStream_t);
 void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
@@ -246,7 +248,7 @@ static SideShade* side_shade() {
 static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
                             int32_t* radii, hipStream_t st, bool defer_color, uint32_t* host_status,
                             hipEvent_t copied /* recorded right behind the status copy, or nullptr */,
-                            SideShade* shade_aside = nullptr) {
+                            SideShade* shade_aside = nullptr, bool tile_local = false) {
   const int P = g->P;
   const GsrGeomLayout L = gsr_geom_layout(P);
   if (!geometry_state || geometry_bytes < L.total) {
@@ -273,10 +275,18 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   // a blocking caller waits for the two words while the GPU still has work queued (no idle gap at the read-back), a
   // non-blocking caller looks at them whenever it likes.
   gsr_launch_sum_tiles(P, geom, L, meta, st);
-  if (host_status &&
+  if (host_status && !tile_local &&
       (rc = gsr_check(hipMemcpyAsync(host_status, meta, 16, hipMemcpyDeviceToHost, st), "read num_rendered")))
     return rc;
   if (copied && (rc = gsr_check(hipEventRecord(copied, st), "record read-back event"))) return rc;
+
+  if (tile_local) {
+    // second form of the binning stage (binning.hip, k_tile_depth_sort): no global depth order; the tile counts are scanned
+    // in index order (no gather) and the instances are emitted in index order
+    gsr_scan_u32((const uint32_t*)(geom + L.tiles_touched), nullptr, (uint32_t*)(geom + L.offsets), (size_t)P, 1,
+                 (uint32_t*)(geom + L.scan_tmp), st);
+    return debug_sync(s, st, "tile-count scan");
+  }
 
   // depth order of the Gaussians (stable, so equal depths keep ascending id); 4 passes -> result in (depth_key, order)
   const int where = gsr_radix_sort_pairs((uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order),
@@ -343,7 +353,8 @@ int gsr_forward_shade(const gsr_settings* s, const gsr_gaussians* g, void* geome
 static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
                                size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
                                float* out_color, float* out_invdepth, bool for_backward, bool shade_late,
-                               hipEvent_t sh_ready, void* stream) {
+                               hipEvent_t sh_ready, void* stream, bool tile_local = false,
+                               uint32_t* host_status_late = nullptr) {
   int rc = validate(s, g);
   if (rc) return rc;
   if (num_rendered < 0 || num_rendered > 0x3FFFFFFFll) {   // the tile sort counts keys in 30-bit fields (sort_scan.hip)
@@ -370,7 +381,7 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   if (R == 0 || g->P == 0) {   // nothing to emit: every tile range is empty (otherwise the emit kernel clears them on its way)
     if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
   } else {
-    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, st);
+    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, st);
     if ((rc = debug_sync(s, st, "emit instances"))) return rc;
     // With a backward to follow, the sort carries (emission slot, Gaussian id): the slot of every list position is where the
     // backward stores that instance's gradient record.  A forward-only render (torch.no_grad) needs the ids alone: they
@@ -389,7 +400,23 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
     const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
     gsr_launch_finalize((uint32_t)R, n_dev, ks, bin, BL, st);
     if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
+    if (tile_local) {
+      // every tile orders its own list by (depth bits, id); the free halves of the tile sort's ping-pong buffers serve the
+      // (slow) path for lists beyond the LDS capacity
+      uint32_t* free_k = (uint32_t*)(bin + (where ? BL.key_a : BL.key_b));
+      uint32_t* free_w = (uint32_t*)(bin + (where ? BL.gauss_of_slot : BL.point_list));
+      uint32_t* free_v = (uint32_t*)(bin + (for_backward ? (where ? BL.val_a : BL.val_b) : BL.val_a));
+      uint32_t* slots = for_backward ? (uint32_t*)(bin + (where ? BL.val_b : BL.val_a)) : nullptr;
+      gsr_launch_tile_depth_sort(tiles, for_backward, (const uint2*)(bin + BL.ranges),
+                                 (uint32_t*)(bin + point_list_offset(BL, tiles)), slots,
+                                 (const uint32_t*)(geom + GL.depth_key), free_k, free_v, free_w,
+                                 (uint32_t*)(geom + GL.meta), st);
+      if ((rc = debug_sync(s, st, "tile depth sort"))) return rc;
+    }
   }
+  if (host_status_late && g->P > 0 &&
+      (rc = gsr_check(hipMemcpyAsync(host_status_late, geom + GL.meta, 32, hipMemcpyDeviceToHost, st), "read status")))
+    return rc;
   if (!shade_late && sh_ready && g->P > 0) {   // colours were evaluated on a side stream: join it
     if ((rc = gsr_check(hipStreamWaitEvent(st, sh_ready, 0), "join shade"))) return rc;
   }
@@ -425,24 +452,29 @@ int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void
 int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
                       int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
                       size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
-                      int32_t defer_color, void* sh_ready_event, uint32_t* host_status, void* stream) {
+                      int32_t defer_color, void* sh_ready_event, uint32_t* host_status, int32_t tile_local_sort,
+                      void* stream) {
   int rc = validate(s, g);
   if (rc) return rc;
+  const bool tlo = tile_local_sort != 0;
   if (g->P > 0) {
     const bool late = defer_color != 0 && !g->colors_precomp;
     static const int aside_env = getenv("GSR_SHADE_STREAM") ? atoi(getenv("GSR_SHADE_STREAM")) : -1;
     const bool want_aside = aside_env < 0 ? g->P >= 200000 : aside_env != 0;
     SideShade* aside = (want_aside && !late && !g->colors_precomp && (g->shs || g->dc) && !s->debug) ? side_shade() : nullptr;
     if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late || aside != nullptr,
-                               host_status, nullptr, aside)))
+                               host_status, nullptr, aside, tlo)))
       return rc;
+    // (tile-local form: the status words - num_rendered AND the longest tile list, meta[4] - are copied at the END)
     if (aside) {
       rc = forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
-                               out_color, out_invdepth, for_backward != 0, false, aside->join, stream);
+                               out_color, out_invdepth, for_backward != 0, false, aside->join, stream, tlo,
+                               tlo ? host_status : nullptr);
       return rc;
     }
     return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
-                               out_color, out_invdepth, for_backward != 0, late, (hipEvent_t)sh_ready_event, stream);
+                               out_color, out_invdepth, for_backward != 0, late, (hipEvent_t)sh_ready_event, stream, tlo,
+                               tlo ? host_status : nullptr);
   }
   return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, 0, image_state, image_bytes, out_color,
                              out_invdepth, for_backward != 0, false, nullptr, stream);

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
   const uint32_t count = offsets_incl[jlast] - slot0;            // block-uniform
   const bool staged = count <= EMIT_WINDOW;
   if (j < P) {
-    const uint32_t g = order[j];
+    const uint32_t g = order ? order[j] : (uint32_t)j;      // (tile-local ordering form: emission in index order)
     const uint32_t incl = offsets_incl[j];
     const uint32_t n = incl - (j == 0 ? 0u : offsets_incl[j - 1]);   // = tiles_touched[g], without a gather
     if (n != 0) {  // culled Gaussians sort to the end (key 0xFFFFFFFF) and emit nothing
@@ -108,12 +108,227 @@ __global__ __launch_bounds__(256) void k_finalize_bins(uint32_t cap, const uint3
   if (pos == R - 1) ranges[t].y = R;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tile-local depth ordering (second form of the binning stage, gsr_forward_async(tile_local_sort = 1)).
+//
+// The first form depth-sorts all P Gaussians (4 radix passes, each paying ~15 us of inter-workgroup coordination at 1 M keys
+// for 16 MB of traffic), scans their tile counts through a gather and emits in depth order, so that the STABLE tile sort
+// leaves every tile's list in (depth, id) order.  Here nothing global is ordered by depth: instances are emitted in INDEX
+// order (coalesced record reads, a plain scan), the same stable tile sort leaves every list in id order, and one workgroup per
+// tile orders ITS list by (depth bits, position) - position = id order, so ties break exactly as before - in LDS with a
+// bitonic network on 64-bit keys, then permutes the list (and the emission slots the backward needs) in place.  ~550 entries
+// per tile at C3.  Lists longer than GSR_TLO_CAP are ordered by the same network in global memory (the two free ping-pong
+// halves of the tile sort hold depth bits and positions): correct, slow, and reported (meta[4] = longest list) so that the
+// caller goes back to the first form for scenes that need it.  Results are bit-identical to the first form.
+// ---------------------------------------------------------------------------------------------------------------
+#define GSR_TLO_CAP 4096
+#define GSR_TLO_SMALL 1024
+#ifndef GSR_TLO_SPLIT
+#define GSR_TLO_SPLIT 1      // lists up to GSR_TLO_SMALL in a launch of their own with a quarter of the LDS (more tiles in flight per CU)
+#endif
+template <bool DUAL, int CAP, int ABOVE>
+__global__ __launch_bounds__(256) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
+                                                         uint32_t* __restrict__ slot_of_pos,
+                                                         const uint32_t* __restrict__ depth_key, uint32_t* __restrict__ free_a,
+                                                         uint32_t* __restrict__ free_b, uint32_t* __restrict__ free_c,
+                                                         uint32_t* __restrict__ meta) {
+  // LDS path: stable LSD radix sort of the list's 32-bit depth keys (8-bit digits, passes whose digit is the same for every
+  // key are skipped - the keys of one tile usually differ in their low ~20 bits only), ranked like the global sort: each
+  // wave ranks a contiguous quarter of the list with ballots and wave-private counters.  The position in the id-ordered
+  // input rides along, so equal depths keep ascending id.  Linear in the list length (a bitonic network on the same data
+  // moved 20x the bytes through LDS and took 0.17 ms per frame at C3).
+  __shared__ uint32_t skey[CAP];                   // one buffer: a pass reads its elements into registers, then scatters
+  __shared__ uint16_t sidx[CAP];
+  __shared__ uint32_t wave_run[4][256];
+  __shared__ uint32_t dstart[256];
+  __shared__ uint32_t red[4], scan4[4];
+  const uint2 range = ranges[blockIdx.x];
+  const uint32_t x = range.x, n = range.y - range.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (n <= 1u || n <= (uint32_t)ABOVE) return;              // block-uniform (ABOVE: the lists another launch orders)
+  if (CAP < GSR_TLO_CAP && n > (uint32_t)CAP) return;
+  // longest list of this frame, for the caller's choice of binning form - only lists past half the LDS capacity report
+  // (same-address atomics cost ~15 ns each on this part: one per tile would be 0.12 ms at 1080p)
+  if (CAP == GSR_TLO_CAP && tid == 0 && n > GSR_TLO_CAP / 2) atomicMax(&meta[4], n);
+  if (n <= (uint32_t)CAP) {
+    uint32_t diff = 0, k0 = 0;
+    for (uint32_t i = tid; i < n; i += 256) {
+      const uint32_t g = point_list[x + i];
+      const uint32_t d = g != 0xFFFFFFFFu ? depth_key[g] : 0xFFFFFFFFu;   // (padding slot of k_emit_instances: last)
+      skey[i] = d;
+      sidx[i] = (uint16_t)i;
+      if (i == (uint32_t)tid) k0 = d;
+      diff |= d ^ k0;                                        // bits in which this thread's keys differ from its first one
+    }
+    // bits in which ANY two keys of the list differ: OR over threads of (own differences | own first key ^ thread 0's first key)
+    __syncthreads();
+    diff |= (tid < (int)n ? k0 : skey[0]) ^ skey[0];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) diff |= __shfl_xor(diff, d, 64);
+    if (lane == 0) red[w] = diff;
+    __syncthreads();
+    diff = red[0] | red[1] | red[2] | red[3];
+    const uint32_t q = (((n + 3) >> 2) + 63) & ~63u;         // elements per wave (multiple of 64)
+    const uint32_t lo = min(n, (uint32_t)w * q), hi = min(n, lo + q);
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int shift = 0; shift < 32; shift += 8) {
+      if (((diff >> shift) & 0xFFu) == 0u) continue;          // every key has the same digit here: identity pass
+      wave_run[0][tid] = 0; wave_run[1][tid] = 0; wave_run[2][tid] = 0; wave_run[3][tid] = 0;
+      __syncthreads();
+      uint32_t rk[CAP / 256], kreg[CAP / 256];   // rk: digit << 24 | input position << 12 | rank in (wave, digit)
+#pragma unroll
+      for (int sb = 0; sb < CAP / 256; sb++) {
+        const uint32_t i = lo + (uint32_t)sb * 64 + lane;
+        rk[sb] = 0; kreg[sb] = 0;
+        if (lo + (uint32_t)sb * 64 < hi) {                    // wave-uniform
+          const bool active = i < hi;
+          kreg[sb] = active ? skey[i] : 0u;
+          const uint32_t src = active ? (uint32_t)sidx[i] : 0u;
+          const uint32_t d = (kreg[sb] >> shift) & 0xFFu;
+          unsigned long long peers = __ballot(active);
+#pragma unroll
+          for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(active && bit);
+            peers &= bit ? bal : ~bal;
+          }
+          const uint32_t rank = __popcll(peers & lt_mask);
+          const uint32_t run = wave_run[w][d];
+          rk[sb] = (d << 24) | (src << 12) | (run + rank);    // run + rank < q <= 1024, src < 4096
+          if (active && rank == 0) wave_run[w][d] = run + (uint32_t)__popcll(peers);
+        }
+      }
+      __syncthreads();
+      {
+        const uint32_t c0 = wave_run[0][tid], c1 = wave_run[1][tid], c2 = wave_run[2][tid], c3 = wave_run[3][tid];
+        // exclusive scan of the digit totals over the 256 threads
+        uint32_t v = c0 + c1 + c2 + c3, inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t t = __shfl_up(inc, d, 64);
+          if (lane >= d) inc += t;
+        }
+        if (lane == 63) scan4[w] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (i < w) base += scan4[i];
+        dstart[tid] = base + inc - v;
+        wave_run[0][tid] = 0; wave_run[1][tid] = c0; wave_run[2][tid] = c0 + c1; wave_run[3][tid] = c0 + c1 + c2;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sb = 0; sb < CAP / 256; sb++) {
+        const uint32_t i = lo + (uint32_t)sb * 64 + lane;
+        if (i < hi) {
+          const uint32_t d = rk[sb] >> 24;
+          const uint32_t pos = dstart[d] + wave_run[w][d] + (rk[sb] & 0xFFFu);
+          skey[pos] = kreg[sb];                               // (every element was read before the barriers above)
+          sidx[pos] = (uint16_t)((rk[sb] >> 12) & 0xFFFu);
+        }
+      }
+      __syncthreads();
+    }
+    // permute the payloads in place: every source is read before anything is written
+    uint32_t gsrc[CAP / 256], ssrc[DUAL ? CAP / 256 : 1];
+#pragma unroll
+    for (int u = 0; u < CAP / 256; u++) {
+      const uint32_t i = (uint32_t)u * 256 + tid;
+      if (i < n) {
+        const uint32_t src = sidx[i];
+        gsrc[u] = point_list[x + src];
+        if (DUAL) ssrc[u] = slot_of_pos[x + src];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < CAP / 256; u++) {
+      const uint32_t i = (uint32_t)u * 256 + tid;
+      if (i < n) {
+        point_list[x + i] = gsrc[u];
+        if (DUAL) slot_of_pos[x + i] = ssrc[u];
+      }
+    }
+    return;
+  }
+  uint32_t npad = 2;
+  while (npad < n) npad <<= 1;
+  // ---- a list beyond the LDS capacity: the same network on (free_a = depth bits, free_b = position) in global memory ----
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint32_t g = point_list[x + i];
+    free_a[x + i] = g != 0xFFFFFFFFu ? depth_key[g] : 0xFFFFFFFFu;
+    free_b[x + i] = i;
+  }
+  __syncthreads();
+  // "normalised" bitonic network: every compare-exchange is ascending (the smaller key goes to the lower index), the first
+  // step of each merge pairs p with its mirror k-1-p.  Positions >= n are virtual +infinity: they sit at the top, compare as
+  // the larger partner and therefore never move, so no padding has to exist in memory.
+  auto cmpx = [&](uint32_t i, uint32_t l) __attribute__((always_inline)) {
+    if (l >= n) return;
+    const unsigned long long a = ((unsigned long long)free_a[x + i] << 32) | free_b[x + i];
+    const unsigned long long b = ((unsigned long long)free_a[x + l] << 32) | free_b[x + l];
+    if (a > b) {
+      free_a[x + i] = (uint32_t)(b >> 32); free_b[x + i] = (uint32_t)b;
+      free_a[x + l] = (uint32_t)(a >> 32); free_b[x + l] = (uint32_t)a;
+    }
+  };
+  for (uint32_t k = 2; k <= npad; k <<= 1) {
+    const uint32_t h = k >> 1;
+    for (uint32_t t = tid; t < (npad >> 1); t += 256) {
+      const uint32_t blk = t / h, p = t - blk * h;
+      cmpx(blk * k + p, blk * k + (k - 1 - p));
+    }
+    __syncthreads();
+    for (uint32_t j = h >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = tid; t < (npad >> 1); t += 256) {
+        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        cmpx(i, i | j);
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = tid; i < n; i += 256) free_c[x + i] = point_list[x + free_b[x + i]];
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += 256) point_list[x + i] = free_c[x + i];
+  if (DUAL) {
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) free_c[x + i] = slot_of_pos[x + free_b[x + i]];
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) slot_of_pos[x + i] = free_c[x + i];
+  }
+}
+
+void gsr_launch_tile_depth_sort(int tiles, bool dual, const uint2* ranges, uint32_t* point_list, uint32_t* slot_of_pos,
+                                const uint32_t* depth_key, uint32_t* free_a, uint32_t* free_b, uint32_t* free_c,
+                                uint32_t* meta, hipStream_t st) {
+#if GSR_TLO_SPLIT
+  if (dual) {
+    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<true, GSR_TLO_SMALL, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
+               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+    GSR_LAUNCH("tile_depth_sort_long", (k_tile_depth_sort<true, GSR_TLO_CAP, GSR_TLO_SMALL>), dim3(tiles), dim3(256), 0, st, ranges,
+               point_list, slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+  } else {
+    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<false, GSR_TLO_SMALL, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
+               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+    GSR_LAUNCH("tile_depth_sort_long", (k_tile_depth_sort<false, GSR_TLO_CAP, GSR_TLO_SMALL>), dim3(tiles), dim3(256), 0, st, ranges,
+               point_list, slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+  }
+#else
+  if (dual)
+    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<true, GSR_TLO_CAP, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
+               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+  else
+    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<false, GSR_TLO_CAP, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
+               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+#endif
+}
+
 void gsr_launch_emit(int P, int grid_x, int tiles, const char* geom, const GsrGeomLayout& GL, char* bin,
-                     const GsrBinLayout& BL, uint32_t cap, hipStream_t st) {
+                     const GsrBinLayout& BL, uint32_t cap, bool index_order, hipStream_t st) {
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
-             (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
-             (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot), (uint32_t*)(geom + GL.slot_start), tiles,
-             (uint2*)(bin + BL.ranges), cap, (uint32_t*)(bin + BL.radix_tmp));
+             index_order ? (const uint32_t*)nullptr : (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
+             (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
+             (uint32_t*)(geom + GL.slot_start), tiles, (uint2*)(bin + BL.ranges), cap, (uint32_t*)(bin + BL.radix_tmp));
 }
 
 void gsr_launch_finalize(uint32_t cap, const uint32_t* n_dev, const uint32_t* tile_sorted, char* bin,

@@ -74,7 +74,7 @@ EXPORTS = {
                                            C.c_int32, C.c_void_p, C.c_void_p]),
     "gsr_forward_async": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.POINTER(gsr_grads), C.c_void_p]),

@@ -237,10 +237,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                     R = pool.capacity[key]
                     binning = ws.ensure_binning(lib, P, W, H, R)
                     status = pool.status_slot()
+                    status[2] = 0
+                    tlo = 1 if _ws.tile_local_binning(pool, key) else 0
                     _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
                                                    _C.ptr(binning), binning.numel(), R, _C.ptr(img), img.numel(),
                                                    _C.ptr(color), _C.ptr(invdepth), 1 if needs_grad else 0,
-                                                   1 if split else 0, evh, C.c_void_p(status.data_ptr()), stream))
+                                                   1 if split else 0, evh, C.c_void_p(status.data_ptr()), tlo, stream))
+                    pool.stats["tile_local_frames"] = pool.stats.get("tile_local_frames", 0) + tlo
                     done = torch.cuda.Event()
                     done.record()
                     pool.pending.append((done, status, R, key))

@@ -6,7 +6,8 @@ allocator growing for a whole pass over the views.  Here every in-flight forward
 (geometry / binning / image state + the backward's gradient records) from a per-device pool; buffers only ever grow
 (geometrically), and once the instance count of a shape (P, W, H) is known the forward goes through `gsr_forward_async`:
 no wait, `num_rendered` arrives in pinned memory and is looked at by a LATER call (`Pool.poll`), where it raises the capacity
-estimate for the next frames.  A frame whose count exceeds the estimate loses its farthest instances (include/gsr.h,
+estimate for the next frames.  A frame whose count exceeds the estimate loses instances (the farthest ones in the global binning
+form, arbitrary ones in the tile-local form, which is why that form waits for a settled capacity; include/gsr.h,
 gsr_forward_async) and is counted in `stats["overflow_frames"]`; `set_forward_mode("sync")` / GSR_FORWARD_MODE=sync keeps the
 blocking read-back for callers that cannot accept that.
 """
@@ -22,6 +23,14 @@ import torch
 from . import _C
 
 _MODE = os.environ.get("GSR_FORWARD_MODE", "async").lower()
+# binning form of the non-blocking forward: "tile" (tile-local depth ordering, include/gsr.h gsr_forward_async) unless a
+# shape's lists get too long for it, or "global" (GSR_BINNING=global: always the global depth sort of the blocking path)
+_BINNING = os.environ.get("GSR_BINNING", "tile").lower()
+TLO_MAX_LIST = 3072      # 75 % of the kernel's LDS capacity (4096 entries): beyond that a shape goes back to the global form
+# The tile-local form emits in index order, so a frame beyond the capacity loses ARBITRARY instances where the global form
+# loses the farthest ones (usually invisible).  It is therefore used only once a shape's capacity has held for this many
+# consecutive frames (GSR_TLO_SETTLE); any raise of the capacity starts the count again.
+TLO_SETTLE_FRAMES = int(os.environ.get("GSR_TLO_SETTLE", "3"))
 HEADROOM = 1.25          # capacity = max(num_rendered seen for this shape) * HEADROOM
 MIN_CAPACITY = 1 << 14
 
@@ -37,6 +46,11 @@ def set_forward_mode(mode: str):
 
 def forward_mode() -> str:
     return _MODE
+
+
+def tile_local_binning(pool, key) -> bool:
+    return (_BINNING == "tile" and pool.longest_list.get(key, 0) <= TLO_MAX_LIST
+            and pool.settled.get(key, 0) >= TLO_SETTLE_FRAMES)
 
 
 def _capacity_for(R: int) -> int:
@@ -96,6 +110,8 @@ class Pool:
         self.lock = threading.Lock()
         self.free = []
         self.capacity = {}                       # (P, W, H) -> instances the binning state is sized for
+        self.longest_list = {}                   # (P, W, H) -> longest tile list seen (tile-local binning form)
+        self.settled = {}                        # (P, W, H) -> frames noted since the capacity last changed
         self.pending = collections.deque()       # (event, pinned status, capacity used, key)
         self.status_free = []
         self.stats = {"num_rendered": 0, "overflow_frames": 0, "async_frames": 0, "sync_frames": 0}
@@ -128,13 +144,21 @@ class Pool:
     def status_slot(self):
         if self.status_free:
             return self.status_free.pop()
-        return torch.zeros(2, dtype=torch.int64).pin_memory()    # [flags word 0|1, num_rendered]
+        return torch.zeros(4, dtype=torch.int64).pin_memory()    # [flags word 0|1, num_rendered, longest list|-, -]
 
     def note(self, key, R):
         self.stats["num_rendered"] = int(R)
         cap = self.capacity.get(key)
         if cap is None or R * 1.1 > cap:
             self.capacity[key] = _capacity_for(R)
+            self.settled[key] = 0
+        else:
+            self.settled[key] = self.settled.get(key, 0) + 1
+
+    def forget_estimates(self):
+        """Drops what was learnt per shape (capacities, list lengths): the next frame of every shape blocks once again."""
+        self.poll(wait=True)
+        self.capacity.clear(); self.longest_list.clear(); self.settled.clear()
 
     def poll(self, wait=False):
         """Looks at the statuses of earlier non-blocking forwards that have completed (all of them with wait=True)."""
@@ -146,6 +170,8 @@ class Pool:
                 break
             self.pending.popleft()
             flags, R = int(status[0]), int(status[1])
+            longest = int(status[2]) & 0xFFFFFFFF
+            self.longest_list[key] = max(self.longest_list.get(key, 0), longest)
             self.status_free.append(status)
             if (flags >> 32) & 1:
                 raise _C.GsrError("Point is filtered although prefiltered is set. This shouldn't happen!")
@@ -153,8 +179,9 @@ class Pool:
                 self.stats["overflow_frames"] += 1
                 if not self._warned:
                     self._warned = True
-                    warnings.warn(f"gsr: a frame had {R} tile instances, capacity was {cap}: its farthest instances were "
-                                  "dropped; the capacity has been raised (GSR_FORWARD_MODE=sync avoids this)")
+                    warnings.warn(f"gsr: a frame had {R} tile instances, capacity was {cap}: the instances beyond it "
+                                  "(the farthest ones, or arbitrary ones in the tile-local binning form) were dropped "
+                                  "for that frame; the capacity has been raised (GSR_FORWARD_MODE=sync avoids this)")
             self.note(key, R if R >= 0 else 0x7FFFFFFF // 2)
 
 

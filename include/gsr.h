@@ -152,16 +152,23 @@ int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void
  * num_rendered stays on the device and every later stage reads min(num_rendered, capacity) from there.  If a frame has MORE
  * instances than `capacity`, the surplus - emitted last, i.e. its farthest splats - is dropped for that frame (never an
  * out-of-bounds access); the caller learns it from `host_status` and grows its buffers for the next frame.
- *   host_status: NULL or 4 words of PINNED host memory, filled asynchronously on `stream` once the projection has run:
- *                [0] reserved, [1] bit 0 = a prefiltered point failed the near-plane test, [2],[3] = num_rendered (lo, hi).
- *                Read it after an event recorded behind this call has completed.
+ *   host_status: NULL or 8 words of PINNED host memory, filled asynchronously on `stream`:
+ *                [0] reserved, [1] bit 0 = a prefiltered point failed the near-plane test, [2],[3] = num_rendered (lo, hi),
+ *                [4] = longest tile list of the frame if it exceeds 2048 entries, else 0 (tile_local_sort only).  Read it after an event recorded behind this call
+ *                has completed.
+ *   tile_local_sort: 0 = the binning of the blocking path (global depth sort of the Gaussians, emission in depth order, stable
+ *                tile sort).  1 = no global depth order: emission in index order, the same stable tile sort, then every
+ *                tile orders ITS list by (depth bits, id) in LDS (binning.hip, k_tile_depth_sort) - identical lists, about
+ *                0.1 ms less at 1 M Gaussians; lists longer than 4096 entries take a slow in-memory path, so a caller should
+ *                fall back to 0 when host_status[4] approaches that (diff_gaussian_rasterization/_workspace.py does).
  *   defer_color / sh_ready_event: as gsr_forward_prepare_geometry + gsr_forward_render_shade (0 / NULL: fused colour pass).
  * The matching gsr_backward takes `capacity` as its num_rendered.  Same kernels, same results as the blocking pair whenever
  * num_rendered <= capacity. */
 int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
                       int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
                       size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
-                      int32_t defer_color, void* sh_ready_event, uint32_t* host_status, void* stream);
+                      int32_t defer_color, void* sh_ready_event, uint32_t* host_status, int32_t tile_local_sort,
+                      void* stream);
 
 /* Backward of the calls above.  dL_dinvdepth may be NULL (treated as zero).  `num_rendered`: the value gsr_forward_prepare
  * returned (and gsr_forward_render was given), or the `capacity` given to gsr_forward_async. */

@@ -22,3 +22,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_capacity_estimates(request):
+    """The non-blocking forward sizes its binning state from earlier frames of the same (P, W, H): two tests that share a
+    shape but not a scene would hand each other a wrong capacity (a frame beyond it drops instances).  Every GPU test starts
+    with no estimates, as a fresh process would."""
+    yield
+    if "gpu" in request.keywords:
+        import torch
+        if torch.cuda.is_available():
+            from diff_gaussian_rasterization import _workspace as ws
+            for p in ws._pools.values():
+                p.forget_estimates()

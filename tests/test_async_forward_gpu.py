@@ -46,11 +46,14 @@ def test_async_forward_and_backward_bit_identical_to_blocking():
         dgr.set_forward_mode("async")
 
 
-def test_async_capacity_overflow_is_contained_and_heals():
-    """Force a capacity far below the instance count: the frame renders from a truncated (nearest-first) list without touching
-    memory outside its buffers, the overflow is counted, the capacity is raised, and the following frame is exact."""
+@pytest.mark.parametrize("tile_local", [False, True])
+def test_async_capacity_overflow_is_contained_and_heals(tile_local, monkeypatch):
+    """Force a capacity far below the instance count: the frame renders from a truncated list (nearest-first in the global
+    binning form, lowest ids first in the tile-local form) without touching memory outside its buffers, the overflow is
+    counted, the capacity is raised, and the following frame is exact."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _workspace as ws
+    monkeypatch.setattr(ws, "TLO_SETTLE_FRAMES", 0 if tile_local else 1 << 30)
     raw, cams = _views(n=2, P=5000, W=160, H=96)
     bg = torch.zeros(3)
     gc, gd = upstream_grads(96, 160)
@@ -85,9 +88,11 @@ def test_async_capacity_overflow_is_contained_and_heals():
         ws.MIN_CAPACITY = old_min
 
 
-def test_lowlevel_async_call_matches_blocking_state():
-    """The C ABI directly: gsr_forward_async with a generous capacity leaves the same images, the same sorted lists (first
-    num_rendered entries) and the same tile ranges as the blocking calls."""
+@pytest.mark.parametrize("tlo", [0, 1])
+def test_lowlevel_async_call_matches_blocking_state(tlo):
+    """The C ABI directly: gsr_forward_async with a generous capacity - in both binning forms (tlo = 1: emission in index
+    order + per-tile depth ordering in LDS) - leaves the same images, the same sorted lists (first num_rendered entries) and the
+    same tile ranges as the blocking calls."""
     import ctypes as C
     import math
     from diff_gaussian_rasterization import _C, GaussianRasterizationSettings, _settings_struct, _gauss_struct, _stream
@@ -109,10 +114,10 @@ def test_lowlevel_async_call_matches_blocking_state():
     binning = torch.zeros(lib.gsr_binning_state_bytes(P, W, H, cap), dtype=torch.uint8, device=dev)
     radii = torch.zeros(P, dtype=torch.int32, device=dev)
     color, invd = torch.empty(3, H, W, device=dev), torch.empty(1, H, W, device=dev)
-    status = torch.zeros(2, dtype=torch.int64).pin_memory()
+    status = torch.zeros(4, dtype=torch.int64).pin_memory()
     _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii), _C.ptr(binning),
                                    binning.numel(), cap, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invd), 1, 0, None,
-                                   C.c_void_p(status.data_ptr()), _stream()))
+                                   C.c_void_p(status.data_ptr()), tlo, _stream()))
     torch.cuda.synchronize()
     assert int(status[1]) == a["R"]
     assert torch.equal(color.cpu(), a["color"]) and torch.equal(invd.cpu(), a["invdepth"]) and torch.equal(radii.cpu(), a["radii"])
@@ -122,6 +127,9 @@ def test_lowlevel_async_call_matches_blocking_state():
     pl = _view(binning, pb[0].value, a["R"], torch.int32).numpy().view("uint32")
     rg = _view(binning, pb[1].value, tiles * 2, torch.int32).numpy().view("uint32").reshape(tiles, 2)
     assert (pl == a["point_list"]).all() and (rg == a["ranges"]).all()
+    if tlo:      # the longest tile list is reported once it passes half the LDS capacity of the per-tile sort (else 0)
+        longest = int((rg[:, 1] - rg[:, 0]).max())
+        assert int(status[2]) & 0xFFFFFFFF == (longest if longest > 2048 else 0)
 
 
 def test_parity_suite_with_the_other_backward_form_and_blocking_forward():
@@ -136,9 +144,46 @@ def test_parity_suite_with_the_other_backward_form_and_blocking_forward():
     sel = ["tests/test_parity_gpu.py::test_forward_backward_parity", "tests/test_parity_gpu.py::test_edge_cases",
            "tests/test_parity_gpu.py::test_bitwise_reproducible", "tests/test_parity_gpu.py::test_against_committed_golden",
            "tests/test_parity_gpu.py::test_config4_code_path_small"]
-    for extra, tests in (({"GSR_BWD_FORM": "tile"}, sel),
+    for extra, tests in (({"GSR_BWD_FORM": "tile", "GSR_TLO_SETTLE": "0"}, sel),      # + tile-local binning from frame 2 on
                          ({"GSR_BWD_FORM": "quad", "GSR_FORWARD_MODE": "sync", "GSR_SHADE_STREAM": "1"}, sel[:3])):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + tests, cwd=root, env=env,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (extra, r.stdout[-3000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("P", [9000, 2600])
+def test_tile_local_sort_long_lists_and_policy(P, monkeypatch):
+    """Every Gaussian piled onto the image centre.  P = 9000: tile lists of > 4096 entries take k_tile_depth_sort's in-memory
+    path, and the Python policy (tile-local form first, back to the global form once a shape has shown lists beyond 3072
+    entries) switches.  P = 2600: lists between 1024 and 3072 entries - the second launch of the LDS sort - and no switch.
+    Either way every frame must give the blocking path's images and gradients bit for bit."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _workspace as ws
+    if ws._BINNING != "tile":
+        pytest.skip("GSR_BINNING=global")
+    monkeypatch.setattr(ws, "TLO_SETTLE_FRAMES", 0)   # (normally the form waits until the shape's capacity has held 3 frames)
+    raw = make_gaussians(P, 1, seed=511, scale_factor=0.5)
+    raw.xyz *= 0.02                                   # a 5 cm blob at the origin: every splat covers the central tiles
+    cam = fibonacci_cameras(2, 96, 64, seed=512)[0]
+    bg = torch.tensor([0.0, 0.1, 0.0])
+    gc, gd = upstream_grads(64, 96)
+    dgr.set_forward_mode("sync")
+    ref = run_hip(raw, cam, 1, bg, gc=gc, gd=gd)
+    dgr.set_forward_mode("async")
+    pool = ws.pool(torch.device("cuda", 0))
+    key = (P, 96, 64)
+    pool.longest_list.pop(key, None)
+    n0 = pool.stats.get("tile_local_frames", 0)
+    for it in range(4):
+        out = run_hip(raw, cam, 1, bg, gc=gc, gd=gd)
+        assert torch.equal(out["color"], ref["color"]) and torch.equal(out["invdepth"], ref["invdepth"]), it
+        for k in ref["grads"]:
+            assert torch.equal(out["grads"][k], ref["grads"][k]), (it, k)
+        dgr.call_stats()                              # waits for the frame's status: the policy sees the long lists
+    used = pool.stats.get("tile_local_frames", 0) - n0
+    if P == 9000:
+        assert pool.longest_list[key] > 4096
+        assert 1 <= used < 4                          # first frame(s) tile-local (slow path inside), then the global form
+    else:
+        assert 2048 < pool.longest_list[key] <= ws.TLO_MAX_LIST and used >= 3
