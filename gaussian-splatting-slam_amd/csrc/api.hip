@@ -14,7 +14,8 @@
 
 // launchers defined in the kernel files
 void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool,
-                               hipStream_t);
+                               bool, hipStream_t);
+void gsr_launch_scan_block_sums(int, char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, hipStream_t);
 void gsr_launch_adam_culled_rows(int, int, const char*, const GsrGeomLayout&, const GsrAdamArgs&, hipStream_t);
 int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
@@ -27,7 +28,7 @@ void gsr_launch_tile_depth_sort(int, bool, const uint2*, uint32_t*, uint32_t*, c
 void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
-                           float*, float*, uint32_t*, hipStream_t);
+                           float*, float*, uint32_t*, const uint32_t*, uint32_t*, hipStream_t);
 void gsr_launch_count_pairs(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, uint32_t*,
                             hipStream_t);
 void gsr_launch_render_bwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*,
@@ -243,6 +244,24 @@ static SideShade* side_shade() {
   return ss.ok ? &ss : nullptr;
 }
 
+// Device-side address of a pinned host allocation (hipHostMalloc / torch's pin_memory), nullptr for anything else.  One
+// lookup per distinct slot: callers cycle through a handful of status slots.
+static uint32_t* device_alias_of_pinned(uint32_t* host) {
+  static thread_local struct { uint32_t* h; uint32_t* d; } cache[8] = {};
+  static thread_local int next = 0;
+  for (int i = 0; i < 8; i++)
+    if (cache[i].h == host) return cache[i].d;
+  hipPointerAttribute_t a;
+  uint32_t* dev = nullptr;
+  if (hipPointerGetAttributes(&a, host) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
+    dev = (uint32_t*)a.devicePointer;
+  else
+    (void)hipGetLastError();
+  cache[next].h = host; cache[next].d = dev;
+  next = (next + 1) & 7;
+  return dev;
+}
+
 // Geometry stages of the forward: projection, num_rendered (kept on the device in meta[2..3] and copied to `host_status`),
 // depth order, tile-count prefix sum.  Never waits for the device.
 static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
@@ -262,7 +281,7 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   static_assert(sizeof(uint32_t) == 4, "");
   if ((rc = gsr_check(hipMemsetAsync(meta, 0, 256 + GSR_RADIX_HEAD_WORDS * 4, st), "memset meta"))) return rc;
 
-  gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, st);
+  gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, /*block_sums=*/tile_local, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
   if (shade_aside) {
     if ((rc = gsr_check(hipEventRecord(shade_aside->fork, st), "fork shade"))) return rc;
@@ -274,19 +293,19 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   // num_rendered (meta[2..3]) and the error flags go back to the host NOW, ahead of the depth sort and the offset scan:
   // a blocking caller waits for the two words while the GPU still has work queued (no idle gap at the read-back), a
   // non-blocking caller looks at them whenever it likes.
+  if (tile_local) {
+    // second form of the binning stage (binning.hip, k_tile_depth_sort): no global depth order; the instances are emitted in
+    // index order, so the projection kernel has left per-workgroup instance totals: one single-workgroup scan gives the start
+    // slots and num_rendered, and k_emit_instances finishes the prefix sum itself
+    gsr_launch_scan_block_sums(P, geom, L, meta, st);
+    if (copied && (rc = gsr_check(hipEventRecord(copied, st), "record read-back event"))) return rc;
+    return debug_sync(s, st, "tile-count scan");
+  }
   gsr_launch_sum_tiles(P, geom, L, meta, st);
-  if (host_status && !tile_local &&
+  if (host_status &&
       (rc = gsr_check(hipMemcpyAsync(host_status, meta, 16, hipMemcpyDeviceToHost, st), "read num_rendered")))
     return rc;
   if (copied && (rc = gsr_check(hipEventRecord(copied, st), "record read-back event"))) return rc;
-
-  if (tile_local) {
-    // second form of the binning stage (binning.hip, k_tile_depth_sort): no global depth order; the tile counts are scanned
-    // in index order (no gather) and the instances are emitted in index order
-    gsr_scan_u32((const uint32_t*)(geom + L.tiles_touched), nullptr, (uint32_t*)(geom + L.offsets), (size_t)P, 1,
-                 (uint32_t*)(geom + L.scan_tmp), st);
-    return debug_sync(s, st, "tile-count scan");
-  }
 
   // depth order of the Gaussians (stable, so equal depths keep ascending id); 4 passes -> result in (depth_key, order)
   const int where = gsr_radix_sort_pairs((uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order),
@@ -414,7 +433,10 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
       if ((rc = debug_sync(s, st, "tile depth sort"))) return rc;
     }
   }
-  if (host_status_late && g->P > 0 &&
+  // status words of the non-blocking forward: written by the compositing kernel itself when the caller's slot is pinned
+  // host memory (it is mapped into the device's address space), copied otherwise
+  uint32_t* status_dev = (host_status_late && g->P > 0) ? device_alias_of_pinned(host_status_late) : nullptr;
+  if (host_status_late && g->P > 0 && !status_dev &&
       (rc = gsr_check(hipMemcpyAsync(host_status_late, geom + GL.meta, 32, hipMemcpyDeviceToHost, st), "read status")))
     return rc;
   if (!shade_late && sh_ready && g->P > 0) {   // colours were evaluated on a side stream: join it
@@ -429,7 +451,8 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   }
   gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                         (const float4*)(geom + GL.rec), out_color, out_invdepth, (float*)(img + IL.final_T),
-                        (uint32_t*)(img + IL.n_contrib), st);
+                        (uint32_t*)(img + IL.n_contrib), status_dev ? (const uint32_t*)(geom + GL.meta) : nullptr, status_dev,
+                        st);
   if ((rc = debug_sync(s, st, "render forward"))) return rc;
   return gsr_launch_status("forward");
 }
@@ -463,18 +486,18 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
     const bool want_aside = aside_env < 0 ? g->P >= 200000 : aside_env != 0;
     SideShade* aside = (want_aside && !late && !g->colors_precomp && (g->shs || g->dc) && !s->debug) ? side_shade() : nullptr;
     if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late || aside != nullptr,
-                               host_status, nullptr, aside, tlo)))
+                               nullptr, nullptr, aside, tlo)))
       return rc;
-    // (tile-local form: the status words - num_rendered AND the longest tile list, meta[4] - are copied at the END)
+    // (the status words - flags, num_rendered and, in the tile-local form, the longest tile list meta[4] - leave at the END)
     if (aside) {
       rc = forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
                                out_color, out_invdepth, for_backward != 0, false, aside->join, stream, tlo,
-                               tlo ? host_status : nullptr);
+                               host_status);
       return rc;
     }
     return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
                                out_color, out_invdepth, for_backward != 0, late, (hipEvent_t)sh_ready_event, stream, tlo,
-                               tlo ? host_status : nullptr);
+                               host_status);
   }
   return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, 0, image_state, image_bytes, out_color,
                              out_invdepth, for_backward != 0, false, nullptr, stream);

@@ -17,8 +17,13 @@
 #ifndef EMIT_WINDOW
 #define EMIT_WINDOW 4096
 #endif
+//
+// order == nullptr (tile-local binning form): emission in index order; offsets_incl then holds, per projection workgroup
+// (= per workgroup here), the instance total [b] and the start slot [nb + b] (k_scan_block_sums), and the scan is finished
+// here from tiles_touched.
 __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ offsets_incl,
+                                                        const uint32_t* __restrict__ tiles_touched,
                                                         const float4* __restrict__ bin_rec,
                                                         uint32_t* __restrict__ tile_key,
                                                         uint32_t* __restrict__ gauss_of_slot,
@@ -26,6 +31,7 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
                                                         uint2* __restrict__ ranges, uint32_t cap,
                                                         uint32_t* __restrict__ sort_head) {
   __shared__ uint32_t lkey[EMIT_WINDOW], lgid[EMIT_WINDOW];
+  __shared__ uint32_t wave_tot[4];
   // the tile sort that follows wants its digit histograms and pass tickets zeroed (sort_scan.hip, head_zeroed)
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < GSR_RADIX_HEAD_WORDS; i += 256) sort_head[i] = 0u;
@@ -34,13 +40,33 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
   const int j0 = blockIdx.x * 256;
   const int j = j0 + threadIdx.x;
   const int jlast = min(j0 + 255, P - 1);
-  const uint32_t slot0 = (j0 == 0) ? 0u : offsets_incl[j0 - 1];
-  const uint32_t count = offsets_incl[jlast] - slot0;            // block-uniform
+  uint32_t slot0, count, incl = 0, n = 0;                          // slot0, count: block-uniform
+  if (order) {
+    slot0 = (j0 == 0) ? 0u : offsets_incl[j0 - 1];
+    count = offsets_incl[jlast] - slot0;
+    if (j < P) {
+      incl = offsets_incl[j];
+      n = incl - (j == 0 ? 0u : offsets_incl[j - 1]);              // = tiles_touched[g], without a gather
+    }
+  } else {
+    const int nb = (P + 255) / 256;
+    count = offsets_incl[blockIdx.x];
+    slot0 = offsets_incl[nb + blockIdx.x];
+    n = j < P ? tiles_touched[j] : 0u;
+    uint32_t inc = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if ((threadIdx.x & 63) >= d) inc += t;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    incl = slot0 + inc + (wv > 0 ? wave_tot[0] : 0u) + (wv > 1 ? wave_tot[1] : 0u) + (wv > 2 ? wave_tot[2] : 0u);
+  }
   const bool staged = count <= EMIT_WINDOW;
   if (j < P) {
     const uint32_t g = order ? order[j] : (uint32_t)j;      // (tile-local ordering form: emission in index order)
-    const uint32_t incl = offsets_incl[j];
-    const uint32_t n = incl - (j == 0 ? 0u : offsets_incl[j - 1]);   // = tiles_touched[g], without a gather
     if (n != 0) {  // culled Gaussians sort to the end (key 0xFFFFFFFF) and emit nothing
       uint32_t off = incl - n;
       slot_start[g] = off;
@@ -327,6 +353,7 @@ void gsr_launch_emit(int P, int grid_x, int tiles, const char* geom, const GsrGe
                      const GsrBinLayout& BL, uint32_t cap, bool index_order, hipStream_t st) {
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
              index_order ? (const uint32_t*)nullptr : (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
+             (const uint32_t*)(geom + GL.tiles_touched),
              (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
              (uint32_t*)(geom + GL.slot_start), tiles, (uint2*)(bin + BL.ranges), cap, (uint32_t*)(bin + BL.radix_tmp));
 }

@@ -259,9 +259,10 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     int defer_color, int raw_act, int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
     uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
     float4* __restrict__ bin_rec,
-    uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta) {
+    uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta, uint32_t* __restrict__ block_sums) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
   __shared__ int32_t need_sh[256];     // STAGE: which SH rows of this workgroup will be evaluated
+  __shared__ uint32_t tile_sum[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int S = 3 * sh_stride, Sp = S | 1;
   const bool in_range = idx < P;
@@ -429,6 +430,53 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     tiles_touched[idx] = out_tiles;
     depth_key[idx] = out_key;   // `order` is not written: the depth sort takes value = index on its first pass
   }
+  // tile-local binning form: instances are emitted in index order, so the prefix sum of the tile counts is taken over the
+  // workgroups of THIS kernel: each leaves its total, k_scan_block_sums turns the totals into start slots (and num_rendered),
+  // and k_emit_instances finishes the scan inside its workgroup - one small launch instead of four
+  if (block_sums) {                                                    // (kernel argument: uniform)
+    uint32_t acc = out_tiles;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) tile_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (tile_sum[0] + tile_sum[1]) + (tile_sum[2] + tile_sum[3]);
+  }
+}
+
+// Start slot of every projection workgroup's instances (exclusive prefix sum of block_sums) and num_rendered (64-bit, into
+// meta[2..3]) - ONE workgroup; 3907 sums at 1 M Gaussians.
+__global__ __launch_bounds__(1024) void k_scan_block_sums(int nb, const uint32_t* __restrict__ block_sums,
+                                                         uint32_t* __restrict__ block_offs,
+                                                         unsigned long long* __restrict__ total) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  unsigned long long carry = 0ull;
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < nb ? block_sums[i] : 0u;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned long long pre = carry;
+    for (int k = 0; k < w; k++) pre += wsum[k];
+    if (i < nb) block_offs[i] = (uint32_t)(pre + inc - v);   // (a count beyond 2^30 is refused by the caller: 32 bits suffice)
+    if (tid == 1023) carry_s = pre + inc;
+    __syncthreads();
+    carry = carry_s;
+  }
+  if (tid == 0) *total = carry;
+}
+
+void gsr_launch_scan_block_sums(int P, char* geom, const GsrGeomLayout& L, uint32_t* meta, hipStream_t st) {
+  const int nb = (P + 255) / 256;
+  GSR_LAUNCH("scan_block_sums", k_scan_block_sums, dim3(1), dim3(1024), 0, st, nb, (const uint32_t*)(geom + L.offsets),
+             (uint32_t*)(geom + L.offsets) + nb, reinterpret_cast<unsigned long long*>(meta + 2));
 }
 
 // num_rendered = sum of tiles_touched does not depend on the depth order: summed right after the projection (integer
@@ -1099,8 +1147,10 @@ void gsr_launch_shade(const gsr_settings* s, const gsr_gaussians* g, char* geom,
 #undef GSR_SHADE_ARGS
 }
 
+// block_sums: the tile-local binning form's per-workgroup instance totals go to the head of the (otherwise unused) `offsets`
+// array: [0, nb) totals, [nb, 2 nb) start slots, nb = ceil(P / 256)
 void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, int32_t* radii, char* geom,
-                               const GsrGeomLayout& L, bool defer_color, hipStream_t st) {
+                               const GsrGeomLayout& L, bool defer_color, bool block_sums, hipStream_t st) {
   const int P = g->P;
   size_t lds = 0;
   const bool stage = !defer_color && can_stage_sh(s, g, &lds);
@@ -1110,7 +1160,8 @@ void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, in
       s->tanfovx, s->tanfovy, s->prefiltered, s->antialiasing, (int)defer_color, (int)g->raw_activations, radii,    \
       (float4*)(geom + L.rec),                                                                                       \
       (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles_touched),              \
-      (ushort4*)(geom + L.rect), (float4*)(geom + L.bin_rec), (uint8_t*)(geom + L.clamped), (uint32_t*)(geom + L.meta)
+      (ushort4*)(geom + L.rect), (float4*)(geom + L.bin_rec), (uint8_t*)(geom + L.clamped), (uint32_t*)(geom + L.meta), \
+      block_sums ? (uint32_t*)(geom + L.offsets) : (uint32_t*)nullptr
   if (stage)
     GSR_LAUNCH("preprocess_fwd", k_preprocess_fwd<true>, dim3((P + 255) / 256), dim3(256), lds, st, GSR_PRE_FWD_ARGS);
   else

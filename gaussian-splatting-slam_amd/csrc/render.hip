@@ -141,9 +141,14 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
                                                     const float4* __restrict__ rec, const float* __restrict__ bg,
                                                     float* __restrict__ out_color, float* __restrict__ out_invdepth,
                                                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                    uint32_t* __restrict__ pairs) {
+                                                    uint32_t* __restrict__ pairs,
+                                                    const uint32_t* __restrict__ status_src,
+                                                    uint32_t* __restrict__ status_dst) {
   __shared__ float4 s0[FWD_BATCH + 6], s1[FWD_BATCH + 6], s2[FWD_BATCH];  // +6: the prefetch may touch [n+5]
   const int tile = blockIdx.x;
+  // non-blocking forward: the frame's status words (flags, num_rendered, longest tile list - final since the previous
+  // kernel) go straight to the caller's pinned host slot; a 32-byte hipMemcpyAsync here cost ~10 us of stream time
+  if (status_dst && blockIdx.x == 0 && threadIdx.x < 8) status_dst[threadIdx.x] = status_src[threadIdx.x];
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int px = tile_x * GSR_TILE + (w & 1) * 8 + (lane & 7);
@@ -584,15 +589,18 @@ __global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x
 
 void gsr_launch_render_fwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,
                            const uint32_t* point_list, const float4* rec, float* out_color, float* out_invdepth,
-                           float* final_T, uint32_t* n_contrib, hipStream_t st) {
+                           float* final_T, uint32_t* n_contrib, const uint32_t* status_src, uint32_t* status_dst,
+                           hipStream_t st) {
   GSR_LAUNCH("render_fwd", k_render_fwd<false>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
-             ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr);
+             ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr, status_src,
+             status_dst);
 }
 
 void gsr_launch_count_pairs(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges, const uint32_t* point_list,
                             const float4* rec, uint32_t* pairs, hipStream_t st) {
   hipLaunchKernelGGL(k_render_fwd<true>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x, ranges,
-                     point_list, rec, s->bg, (float*)nullptr, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, pairs);
+                     point_list, rec, s->bg, (float*)nullptr, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, pairs,
+                     (const uint32_t*)nullptr, (uint32_t*)nullptr);
 }
 
 void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,

@@ -9,6 +9,18 @@ from .losses import training_loss, training_loss_fused
 from .parallel import GradBucket, reduce_densification_stats
 
 
+class _LazyVisibility:
+    """`render()`'s "visibility_filter" (radii > 0), looked up only by the branches of a step that use it."""
+
+    def __init__(self, pkg, value=None):
+        self.pkg, self.value = pkg, value
+
+    def get(self):
+        if self.value is None:
+            self.value = self.pkg["visibility_filter"]
+        return self.value
+
+
 class Trainer:
     def __init__(self, model, cameras, gt_images, render_fn, pipe, bg, lambda_dssim=0.2, world=1, rank=0,
                  optimizer="hip", loss="hip", depth_targets=None, depth_weight=0.0, separate_sh=False, overlap_comm=None,
@@ -68,6 +80,7 @@ class Trainer:
             self.optimizer.init_state()      # moments live in the main stream's pool, never the side stream's
         self.densify = None          # schedule dict once enable_densification() is called
         self.iteration = 0
+        self._one = None                 # cached dL/dloss = 1 for loss.backward()
         self.last = {}
 
     # statistics live in the model (reference: GaussianModel.xyz_gradient_accum / denom / max_radii2D)
@@ -98,7 +111,8 @@ class Trainer:
         for n, v in enumerate(views):
             cam = self.cameras[v]
             pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh)
-            image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
+            image, vsp, radii = pkg["render"], pkg["viewspace_points"], pkg["radii"]
+            vis = _LazyVisibility(pkg)       # `radii > 0`: only materialised by the branches that use it
             loss = self.loss_fn(image, self.gt_images[v], self.lambda_dssim)
             if self.depth_weight > 0 and self.depth_targets is not None:
                 loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[v]).mean()
@@ -116,7 +130,9 @@ class Trainer:
             if fold:
                 import diff_gaussian_rasterization as dgr
                 dgr.fuse_optimizer_into_next_backward(self.optimizer, split_rows=self.split_rows)
-            loss.backward()                                                                      # .grad accumulates
+            if self._one is None or self._one.device != loss.device:
+                self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+            loss.backward(gradient=self._one)          # .grad accumulates; (a cached seed: no fill launch per step)
             folded = False
             if fold:
                 folded = not dgr.fuse_pending()
@@ -128,11 +144,11 @@ class Trainer:
             if not fold_stats:
                 with torch.no_grad():
                     # densification statistics are per-view: norm BEFORE any cross-rank reduction
-                    self.model.add_densification_stats(vsp, vis, radii)                      # train.py:159-160
+                    self.model.add_densification_stats(vsp, vis.get(), radii)                # train.py:159-160
             if n + 1 < len(views):
-                vis_any = vis if n == 0 else (vis_any | vis)
+                vis_any = vis.get() if n == 0 else (vis_any | vis.get())
         if len(views) > 1:
-            vis = vis_any | vis
+            vis = _LazyVisibility(None, vis_any | vis.get())
         self.iteration += 1
         self.last = dict(loss=loss.detach(), image=image.detach(), radii=radii)
         if len(views) == 1 and folded and self.densify is None:
@@ -142,11 +158,11 @@ class Trainer:
             # the ranks' visibility masks (a Gaussian seen by any rank has a non-zero averaged gradient) - otherwise the
             # replicas would drift apart
             import torch.distributed as dist
-            v8 = vis.to(torch.uint8)
+            v8 = vis.get().to(torch.uint8)
             dist.all_reduce(v8, op=dist.ReduceOp.MAX)
-            vis = v8.bool()
+            vis = _LazyVisibility(None, v8.bool())
         if self.overlap_comm and not self._densify_due():
-            self._exchange_and_step_overlapped(vis, radii)
+            self._exchange_and_step_overlapped(vis.get() if self.optimizer_kind == "hip_sparse" else None, radii)
             return self.last
         if self.sharded is not None:
             if self.densify is not None:
@@ -155,13 +171,13 @@ class Trainer:
             return self.last
         with torch.no_grad():
             if self.bucket is not None:
-                self.bucket.all_reduce_mean(self.world, visible=vis if self.exchange == "visible_rows" else None)
+                self.bucket.all_reduce_mean(self.world, visible=vis.get() if self.exchange == "visible_rows" else None)
             if self.densify is not None:
                 # the reference densifies between backward and the optimizer step (train.py:155-168 before :170): the
                 # replaced Parameters carry no gradient, so the step that follows skips them, exactly like there
                 self._maybe_densify(radii)
             if self.optimizer_kind == "hip_sparse":
-                self.optimizer.step(vis, radii.shape[0])                                       # train.py:173-175
+                self.optimizer.step(vis.get(), radii.shape[0])                                 # train.py:173-175
             else:
                 self.optimizer.step()
             self.optimizer.zero_grad(set_to_none=True)
@@ -198,7 +214,8 @@ class Trainer:
             for p in sh:
                 if p.grad is not None:
                     p.grad.record_stream(side)
-            vis.record_stream(side)
+            if vis is not None:
+                vis.record_stream(side)
             if self.bucket is not None:
                 self.bucket.all_reduce_mean(self.world, params=sh)
             if self.optimizer_kind == "hip_sparse":
