@@ -283,7 +283,10 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
 
   gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, /*block_sums=*/tile_local, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
-  if (shade_aside) {
+  // (tile-local binning form: the colour pass is forked behind the emission instead - forward_render_impl - because the
+  // two are both HBM-bound and slowed each other down (emission 36 -> 55 us); the tile sort and the per-tile ordering that
+  // follow are latency- / issue-bound and share the machine well: -12 us per frame at C3)
+  if (shade_aside && !tile_local) {
     if ((rc = gsr_check(hipEventRecord(shade_aside->fork, st), "fork shade"))) return rc;
     if ((rc = gsr_check(hipStreamWaitEvent(shade_aside->stream, shade_aside->fork, 0), "fork shade"))) return rc;
     gsr_launch_shade(s, g, geom, L, shade_aside->stream);
@@ -401,6 +404,15 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
     if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
   } else {
     gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, st);
+    {
+      SideShade* a = (tile_local && !shade_late && sh_ready) ? side_shade() : nullptr;
+      if (a && sh_ready == a->join) {      // colour pass on the side stream, beside the tile sort (see forward_geometry)
+        if ((rc = gsr_check(hipEventRecord(a->fork, st), "fork shade"))) return rc;
+        if ((rc = gsr_check(hipStreamWaitEvent(a->stream, a->fork, 0), "fork shade"))) return rc;
+        gsr_launch_shade(s, g, (char*)geom, GL, a->stream);
+        if ((rc = gsr_check(hipEventRecord(a->join, a->stream), "join shade"))) return rc;
+      }
+    }
     if ((rc = debug_sync(s, st, "emit instances"))) return rc;
     // With a backward to follow, the sort carries (emission slot, Gaussian id): the slot of every list position is where the
     // backward stores that instance's gradient record.  A forward-only render (torch.no_grad) needs the ids alone: they

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
     __syncthreads();
     // `cap` = instances the binning state has room for.  On the blocking path cap == num_rendered and the guard never
     // fires; on the non-blocking path (gsr_forward_async) a view with more instances than the caller's estimate loses its
-    // LAST slots, i.e. (emission runs in depth order) its farthest splats, instead of writing out of bounds.
+    // LAST slots - its farthest splats when emission runs in depth order, its highest Gaussian indices in the tile-local
+    // form - instead of writing out of bounds.
     const uint32_t lim = slot0 < cap ? min(count, cap - slot0) : 0u;
     for (uint32_t i = threadIdx.x; i < lim; i += 256) {
       tile_key[slot0 + i] = lkey[i];
@@ -140,12 +141,13 @@ __global__ __launch_bounds__(256) void k_finalize_bins(uint32_t cap, const uint3
 // The first form depth-sorts all P Gaussians (4 radix passes, each paying ~15 us of inter-workgroup coordination at 1 M keys
 // for 16 MB of traffic), scans their tile counts through a gather and emits in depth order, so that the STABLE tile sort
 // leaves every tile's list in (depth, id) order.  Here nothing global is ordered by depth: instances are emitted in INDEX
-// order (coalesced record reads, a plain scan), the same stable tile sort leaves every list in id order, and one workgroup per
-// tile orders ITS list by (depth bits, position) - position = id order, so ties break exactly as before - in LDS with a
-// bitonic network on 64-bit keys, then permutes the list (and the emission slots the backward needs) in place.  ~550 entries
-// per tile at C3.  Lists longer than GSR_TLO_CAP are ordered by the same network in global memory (the two free ping-pong
-// halves of the tile sort hold depth bits and positions): correct, slow, and reported (meta[4] = longest list) so that the
-// caller goes back to the first form for scenes that need it.  Results are bit-identical to the first form.
+// order (coalesced record reads; the tile-count scan collapses into the projection and emission kernels plus one
+// single-workgroup launch), the same stable tile sort leaves every list in id order, and one workgroup per tile orders ITS
+// list by (depth bits, position) - position = id order, so ties break exactly as before - with a stable LSD radix sort in
+// LDS, then permutes the list (and the emission slots the backward needs) in place.  ~550 entries per tile at C3.  Lists
+// longer than GSR_TLO_CAP are ordered by a bitonic network in global memory (the two free ping-pong halves of the tile sort
+// hold depth bits and positions): correct, slow, and reported (meta[4] = longest list) so that the caller goes back to the
+// first form for scenes that need it.  Results are bit-identical to the first form.
 // ---------------------------------------------------------------------------------------------------------------
 #define GSR_TLO_CAP 4096
 #define GSR_TLO_SMALL 1024

@@ -150,17 +150,22 @@ int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void
  * buffers and cannot afford the reference rasterizer's one host read-back per frame (a SLAM / training loop enqueues several
  * frames ahead).  The binning state is sized by the caller for `capacity` instances (gsr_binning_state_bytes(.., capacity));
  * num_rendered stays on the device and every later stage reads min(num_rendered, capacity) from there.  If a frame has MORE
- * instances than `capacity`, the surplus - emitted last, i.e. its farthest splats - is dropped for that frame (never an
- * out-of-bounds access); the caller learns it from `host_status` and grows its buffers for the next frame.
- *   host_status: NULL or 8 words of PINNED host memory, filled asynchronously on `stream`:
+ * instances than `capacity`, the surplus - emitted last: its farthest splats with tile_local_sort = 0, the Gaussians with the
+ * highest indices with tile_local_sort = 1 - is dropped for that frame (never an out-of-bounds access); the caller learns it
+ * from `host_status` and grows its buffers for the next frame.
+ *   host_status: NULL or 8 words of host memory, filled asynchronously on `stream` at the END of the call's work:
  *                [0] reserved, [1] bit 0 = a prefiltered point failed the near-plane test, [2],[3] = num_rendered (lo, hi),
- *                [4] = longest tile list of the frame if it exceeds 2048 entries, else 0 (tile_local_sort only).  Read it after an event recorded behind this call
- *                has completed.
+ *                [4] = longest tile list of the frame if it exceeds 2048 entries, else 0 (tile_local_sort only).
+ *                Pinned memory (hipHostMalloc / torch pin_memory) is written by the compositing kernel itself through its
+ *                device mapping; any other host memory gets a hipMemcpyAsync.  Read it after an event recorded behind this
+ *                call has completed.
  *   tile_local_sort: 0 = the binning of the blocking path (global depth sort of the Gaussians, emission in depth order, stable
  *                tile sort).  1 = no global depth order: emission in index order, the same stable tile sort, then every
  *                tile orders ITS list by (depth bits, id) in LDS (binning.hip, k_tile_depth_sort) - identical lists, about
- *                0.1 ms less at 1 M Gaussians; lists longer than 4096 entries take a slow in-memory path, so a caller should
- *                fall back to 0 when host_status[4] approaches that (diff_gaussian_rasterization/_workspace.py does).
+ *                0.07 ms less per frame at 1 M Gaussians / 1080p (the tile counts are then also scanned inside the projection
+ *                and emission kernels: four launches fewer); lists longer than 4096 entries take a slow in-memory path, so a
+ *                caller should fall back to 0 when host_status[4] approaches that, and should prefer 0 while its capacity
+ *                estimate is still moving (diff_gaussian_rasterization/_workspace.py does both).
  *   defer_color / sh_ready_event: as gsr_forward_prepare_geometry + gsr_forward_render_shade (0 / NULL: fused colour pass).
  * The matching gsr_backward takes `capacity` as its num_rendered.  Same kernels, same results as the blocking pair whenever
  * num_rendered <= capacity. */

@@ -18,6 +18,7 @@ timeout -k 10 300 python3 bench.py --config 5 --densify --densify-from 100 --ste
 timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --optimizer hip > $OUT/bench_c3_adam_unfused.json 2> /dev/null
 timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --optimizer hip_sparse_fused > $OUT/bench_c3_sparse_fused.json 2> /dev/null
 timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --forward-mode sync > $OUT/bench_c3_sync_forward.json 2> /dev/null
+GSR_BINNING=global timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline > $OUT/bench_c3_global_binning.json 2> /dev/null
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python3 $R/bench.py $DRV --no-cpu-baseline > $R/$OUT/stats.json 2> $R/$OUT/stats.err
 PM="--gpus 1 --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-profile --views 8"
