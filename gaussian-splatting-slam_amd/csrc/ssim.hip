@@ -187,8 +187,11 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, Ssim
                                                   const float* __restrict__ dm_dmu1,
                                                   const float* __restrict__ dm_dsigma1_sq,
                                                   const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
+  // The horizontal pass runs IN PLACE: item i = (row i / 8, column group i % 8), so the eight threads of a row sit in one wave
+  // and a wave owns its rows exclusively; every lane of the wave has its 14 taps in registers before the first result is
+  // stored, and no other wave touches those rows.  13 KB of LDS instead of 24 KB: 8 workgroups per CU instead of 6 for a kernel
+  // that spends 60 % of its wave cycles waiting on memory (61 -> 54 us at 1080p).
   __shared__ float sa[3][SHY][SH + 1];
-  __shared__ float hm[3][SHY][ST + 1];
   const int tid = threadIdx.x;
   const SsimTile tile = ssim_tile((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   if (!tile.valid) return;                         // block-uniform
@@ -221,6 +224,10 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, Ssim
     float v0[14], v1[14], v2[14];
 #pragma unroll
     for (int k = 0; k < 14; k++) { v0[k] = sa[0][r][c0 + k]; v1[k] = sa[1][r][c0 + k]; v2[k] = sa[2][r][c0 + k]; }
+    // every load of the wave is issued before its first store (LDS executes a wave's operations in order); the compiler must
+    // not sink a load below a store it can prove disjoint for ONE lane - a neighbouring lane's store hits it
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       float t0 = 0.f, t1 = 0.f, t2 = 0.f;
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, Ssim
         const float w = win.g[k];
         t0 += w * v0[j + k]; t1 += w * v1[j + k]; t2 += w * v2[j + k];
       }
-      hm[0][r][c0 + j] = t0; hm[1][r][c0 + j] = t1; hm[2][r][c0 + j] = t2;
+      sa[0][r][c0 + j] = t0; sa[1][r][c0 + j] = t1; sa[2][r][c0 + j] = t2;      // in place (see above)
     }
   }
   __syncthreads();
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, Ssim
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
-      for (int k = 0; k < RPT + 10; k++) col[q][k] = hm[q][r0 + k][c];
+      for (int k = 0; k < RPT + 10; k++) col[q][k] = sa[q][r0 + k][c];
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const int gy = y0 + r0 + j, gx = x0 + c;

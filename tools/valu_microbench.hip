@@ -20,9 +20,11 @@
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define REP64(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X)
 
-enum { K_FMA = 0, K_EXP, K_DPP, K_SWAP, K_LDS, K_MIX, K_COUNT };
+enum { K_FMA = 0, K_EXP, K_DPP, K_SWAP, K_LDS, K_MIX, K_PKFMA, K_COUNT };
+typedef float f2_t __attribute__((ext_vector_type(2)));
 static const char* kNames[K_COUNT] = {"v_fma_f32", "v_exp_f32", "v_add_f32 dpp row_ror:8", "v_permlane32_swap_b32",
-                                      "ds_read_b128 (broadcast)", "mix 5 fma : 1 exp : 2 dpp-add"};
+                                      "ds_read_b128 (broadcast)", "mix 5 fma : 1 exp : 2 dpp-add",
+                                      "v_pk_fma_f32 (2 fma per lane)"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_bench(int iters, float seed, float* out, unsigned long long* cycles) {
@@ -40,6 +42,12 @@ __global__ __launch_bounds__(256) void k_bench(int iters, float seed, float* out
   for (int it = 0; it < iters; it++) {
     if (KIND == K_FMA) {
 #define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+      REP64(X)
+#undef X
+    } else if (KIND == K_PKFMA) {
+      f2_t* r2 = reinterpret_cast<f2_t*>(r);      // four register pairs
+      const f2_t a2 = {a, a}, b2 = {b, b};
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r2[(i) & 3]) : "v"(a2), "v"(b2));
       REP64(X)
 #undef X
     } else if (KIND == K_EXP) {
@@ -133,6 +141,7 @@ int main() {
     run<K_SWAP>(k, iters, out, cyc, host);
     run<K_LDS>(k, iters, out, cyc, host);
     run<K_MIX>(k, iters, out, cyc, host);
+    run<K_PKFMA>(k, iters, out, cyc, host);
   }
   CHECK(hipFree(out));
   CHECK(hipFree(cyc));
