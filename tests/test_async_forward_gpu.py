@@ -88,11 +88,12 @@ def test_async_capacity_overflow_is_contained_and_heals(tile_local, monkeypatch)
         ws.MIN_CAPACITY = old_min
 
 
-@pytest.mark.parametrize("tlo", [0, 1])
-def test_lowlevel_async_call_matches_blocking_state(tlo):
+@pytest.mark.parametrize("tlo,pinned", [(0, True), (1, True), (1, False)])
+def test_lowlevel_async_call_matches_blocking_state(tlo, pinned):
     """The C ABI directly: gsr_forward_async with a generous capacity - in both binning forms (tlo = 1: emission in index
     order + per-tile depth ordering in LDS) - leaves the same images, the same sorted lists (first num_rendered entries) and the
-    same tile ranges as the blocking calls."""
+    same tile ranges as the blocking calls.  The status words reach a pinned slot through the compositing kernel's own store
+    and pageable memory through a copy."""
     import ctypes as C
     import math
     from diff_gaussian_rasterization import _C, GaussianRasterizationSettings, _settings_struct, _gauss_struct, _stream
@@ -114,7 +115,9 @@ def test_lowlevel_async_call_matches_blocking_state(tlo):
     binning = torch.zeros(lib.gsr_binning_state_bytes(P, W, H, cap), dtype=torch.uint8, device=dev)
     radii = torch.zeros(P, dtype=torch.int32, device=dev)
     color, invd = torch.empty(3, H, W, device=dev), torch.empty(1, H, W, device=dev)
-    status = torch.zeros(4, dtype=torch.int64).pin_memory()
+    status = torch.zeros(4, dtype=torch.int64)
+    if pinned:
+        status = status.pin_memory()
     _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii), _C.ptr(binning),
                                    binning.numel(), cap, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invd), 1, 0, None,
                                    C.c_void_p(status.data_ptr()), tlo, _stream()))
