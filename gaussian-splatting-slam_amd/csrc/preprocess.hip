@@ -590,6 +590,9 @@ __device__ __forceinline__ void adam_row(const GsrAdamArgs& A, const int grp, co
   for (int j = 0; j < N; j++) { P[j] = p[j]; M[j] = m[j]; V[j] = v[j]; }
 }
 
+#ifndef GSR_ADAM_AHEAD
+#define GSR_ADAM_AHEAD 6      // trips of f_rest moments in flight ahead of the one being updated (2 -> 6: -2 % of the kernel)
+#endif
 template <bool STAGE, int ADAM>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int P, int deg, int sh_stride, const float* __restrict__ means3D, const float* __restrict__ dc,
@@ -911,16 +914,20 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       float* Mg = A.m[2] + row0 * S;
       float* Vg = A.v[2] + row0 * S;
       if (ADAM == 1) {
-        // every piece is updated: the moments of the next TWO trips are in flight while this one is computed and stored (the
+        // every piece is updated: the moments of the next GSR_ADAM_AHEAD trips are in flight while this one is computed and stored (the
         // loop is pure streaming - 32 B in, 48 B out per piece - and with two workgroups per CU it lives on loads in flight)
-        gsr_f4 mq[3], vq[3];
+        constexpr int AHEAD = GSR_ADAM_AHEAD;
+        gsr_f4 mq[AHEAD + 1], vq[AHEAD + 1];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < AHEAD; u++) {
           const int iu = threadIdx.x + 256 * u;
           if (iu < n4) { mq[u] = gsr_ld_stream(Mg + 4 * (size_t)iu); vq[u] = gsr_ld_stream(Vg + 4 * (size_t)iu); }
         }
         for (int i = threadIdx.x; i < n4; i += 256) {
-          if (i + 512 < n4) { mq[2] = gsr_ld_stream(Mg + 4 * (size_t)(i + 512)); vq[2] = gsr_ld_stream(Vg + 4 * (size_t)(i + 512)); }
+          if (i + 256 * AHEAD < n4) {
+            mq[AHEAD] = gsr_ld_stream(Mg + 4 * (size_t)(i + 256 * AHEAD));
+            vq[AHEAD] = gsr_ld_stream(Vg + 4 * (size_t)(i + 256 * AHEAD));
+          }
           float pp[4], mm[4] = {mq[0].x, mq[0].y, mq[0].z, mq[0].w}, vv[4] = {vq[0].x, vq[0].y, vq[0].z, vq[0].w};
           int rr = r, cc = c;
 #pragma unroll
@@ -933,7 +940,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
           gsr_st_stream(Pg + 4 * (size_t)i, gsr_f4{pp[0], pp[1], pp[2], pp[3]});
           gsr_st_stream(Mg + 4 * (size_t)i, gsr_f4{mm[0], mm[1], mm[2], mm[3]});
           gsr_st_stream(Vg + 4 * (size_t)i, gsr_f4{vv[0], vv[1], vv[2], vv[3]});
-          mq[0] = mq[1]; vq[0] = vq[1]; mq[1] = mq[2]; vq[1] = vq[2];
+#pragma unroll
+          for (int u = 0; u < AHEAD; u++) { mq[u] = mq[u + 1]; vq[u] = vq[u + 1]; }
           r += dr; c += dcol;
           if (c >= S) { c -= S; r++; }
         }
