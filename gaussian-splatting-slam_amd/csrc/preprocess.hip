@@ -889,13 +889,27 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     // ---- optimizer step instead of gradient stores (raw-parameter call form: the gradients above ARE the leaves') ----
     const bool upd = active && (ADAM == 1 || (ADAM == 2 ? radii[idx] > 0 : visible));
     if (upd) {
-      adam_row<ADAM, 3>(A, 0, (size_t)idx, g_mean);
+      // the five small groups (xyz 3, f_dc 3, opacity 1, scaling 3, rotation 4 elements per row): ALL their parameter and
+      // moment loads first, then the arithmetic, then the stores - group after group exposed a memory round trip each
       const float bk0 = have_sh ? bs[0] : 0.f;
-      const float g_dc[3] = {bk0 * g_col[0], bk0 * g_col[1], bk0 * g_col[2]};
-      adam_row<ADAM, 3>(A, 1, (size_t)idx, g_dc);
-      adam_row<ADAM, 1>(A, 3, (size_t)idx, &g_opac);
-      adam_row<ADAM, 3>(A, 4, (size_t)idx, g_scale);
-      adam_row<ADAM, 4>(A, 5, (size_t)idx, g_rot);
+      const float gg[14] = {g_mean[0], g_mean[1], g_mean[2], bk0 * g_col[0], bk0 * g_col[1], bk0 * g_col[2], g_opac,
+                            g_scale[0], g_scale[1], g_scale[2], g_rot[0], g_rot[1], g_rot[2], g_rot[3]};
+      constexpr int GRP[14] = {0, 0, 0, 1, 1, 1, 3, 4, 4, 4, 5, 5, 5, 5};
+      constexpr int WID[14] = {3, 3, 3, 3, 3, 3, 1, 3, 3, 3, 4, 4, 4, 4};
+      constexpr int COL[14] = {0, 1, 2, 0, 1, 2, 0, 0, 1, 2, 0, 1, 2, 3};
+      float pv[14], mv[14], vv[14];
+#pragma unroll
+      for (int e = 0; e < 14; e++) {
+        const size_t o = (size_t)WID[e] * idx + COL[e];
+        pv[e] = A.p[GRP[e]][o]; mv[e] = A.m[GRP[e]][o]; vv[e] = A.v[GRP[e]][o];
+      }
+#pragma unroll
+      for (int e = 0; e < 14; e++) adam_elem<ADAM == 2 ? 2 : 1>(pv[e], mv[e], vv[e], gg[e], A, GRP[e]);
+#pragma unroll
+      for (int e = 0; e < 14; e++) {
+        const size_t o = (size_t)WID[e] * idx + COL[e];
+        A.p[GRP[e]][o] = pv[e]; A.m[GRP[e]][o] = mv[e]; A.v[GRP[e]][o] = vv[e];
+      }
     }
     if (STAGE) {
       // f_rest: dL/dsh[k][c] = basis_k * dL/drgb_c is rank one, so a row's gradient is 19 numbers (basis values, masked
