@@ -244,22 +244,14 @@ static SideShade* side_shade() {
   return ss.ok ? &ss : nullptr;
 }
 
-// Device-side address of a pinned host allocation (hipHostMalloc / torch's pin_memory), nullptr for anything else.  One
-// lookup per distinct slot: callers cycle through a handful of status slots.
+// Device-side address of a pinned host allocation (hipHostMalloc / torch's pin_memory), nullptr for anything else.  Queried on
+// every call (~1 us): a cached answer would go stale if the caller freed the slot and the address came back as pageable memory.
 static uint32_t* device_alias_of_pinned(uint32_t* host) {
-  static thread_local struct { uint32_t* h; uint32_t* d; } cache[8] = {};
-  static thread_local int next = 0;
-  for (int i = 0; i < 8; i++)
-    if (cache[i].h == host) return cache[i].d;
   hipPointerAttribute_t a;
-  uint32_t* dev = nullptr;
   if (hipPointerGetAttributes(&a, host) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
-    dev = (uint32_t*)a.devicePointer;
-  else
-    (void)hipGetLastError();
-  cache[next].h = host; cache[next].d = dev;
-  next = (next + 1) & 7;
-  return dev;
+    return (uint32_t*)a.devicePointer;
+  (void)hipGetLastError();
+  return nullptr;
 }
 
 // Geometry stages of the forward: projection, num_rendered (kept on the device in meta[2..3] and copied to `host_status`),
