@@ -152,10 +152,11 @@ __device__ __forceinline__ float sh_coef(const float* dc, const float* shs, int 
 // bench scene and most of a room-scale capture - are not fetched; their LDS rows stay undefined.  All the loads of a thread
 // are issued before the first LDS store (a predicated load followed by its own store would serialise the fetches).
 #define GSR_STAGE_MAX_TRIPS 16     // 256 rows x S floats / 4 / 256 threads = S / 4 <= 16 (can_stage_sh caps S at 63)
+template <int BT = 256>
 __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int nflt, int S, int Sp, float* lds,
                                               const int32_t* need = nullptr) {
   const int n4 = nflt >> 2;
-  const int dr = 1024 / S, dc = 1024 - dr * S;                 // (row, column) advance per trip
+  const int dr = (4 * BT) / S, dc = (4 * BT) - dr * S;                 // (row, column) advance per trip
   const int r0 = (threadIdx.x * 4) / S, c0 = threadIdx.x * 4 - r0 * S;
   float4 v[GSR_STAGE_MAX_TRIPS];
   bool want[GSR_STAGE_MAX_TRIPS];
@@ -163,7 +164,7 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int
     int r = r0, c = c0;
 #pragma unroll
     for (int it = 0; it < GSR_STAGE_MAX_TRIPS; it++) {
-      const int i = threadIdx.x + 256 * it;
+      const int i = threadIdx.x + BT * it;
       want[it] = i < n4;
       if (want[it] && need) want[it] = need[r] > 0 || (c + 3 >= S && (r + 1) * S < nflt && need[r + 1] > 0);   // may straddle 2 rows
       if (want[it]) v[it] = gsr_ld_stream4(reinterpret_cast<const float4*>(src) + i);   // SH rows pass through once per kernel
@@ -188,16 +189,17 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int
       if (c >= S) { c -= S; r++; }
     }
   }
-  for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {
+  for (int e = n4 * 4 + threadIdx.x; e < nflt; e += BT) {
     const int r2 = e / S, c2 = e - r2 * S;
     lds[r2 * Sp + c2] = src[e];
   }
 }
+template <int BT = 256>
 __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, int nflt, int S, int Sp, const float* lds) {
   const int n4 = nflt >> 2;
-  const int dr = 1024 / S, dc = 1024 - dr * S;
+  const int dr = (4 * BT) / S, dc = (4 * BT) - dr * S;
   int r = (threadIdx.x * 4) / S, c = threadIdx.x * 4 - r * S;
-  for (int i = threadIdx.x; i < n4; i += 256) {
+  for (int i = threadIdx.x; i < n4; i += BT) {
     int rr = r, cc = c;
     float vv[4];
 #pragma unroll
@@ -209,7 +211,7 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, int nflt
     r += dr; c += dc;
     if (c >= S) { c -= S; r++; }
   }
-  for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {
+  for (int e = n4 * 4 + threadIdx.x; e < nflt; e += BT) {
     const int r2 = e / S, c2 = e - r2 * S;
     dst[e] = lds[r2 * Sp + c2];
   }
@@ -590,11 +592,17 @@ __device__ __forceinline__ void adam_row(const GsrAdamArgs& A, const int grp, co
   for (int j = 0; j < N; j++) { P[j] = p[j]; M[j] = m[j]; V[j] = v[j]; }
 }
 
+#ifndef GSR_BWD_ADAM_BT
+#define GSR_BWD_ADAM_BT 64    // Gaussians per workgroup of the folded-optimizer backward with staged SH rows (256 / 128 / 64: 0.351 / 0.347 / 0.337 ms at C3)
+#endif
 #ifndef GSR_ADAM_AHEAD
 #define GSR_ADAM_AHEAD 6      // trips of f_rest moments in flight ahead of the one being updated (2 -> 6: -2 % of the kernel)
 #endif
-template <bool STAGE, int ADAM>
-__global__ __launch_bounds__(256) void k_preprocess_bwd(
+// BT = Gaussians (threads) per workgroup.  The folded-optimizer instantiations stage 64 floats per row in LDS: 256-row workgroups
+// fit two per CU, one-wave workgroups of 64 rows eight or nine - the same waves, but four times as many independent phases
+// (gather / arithmetic / streaming) in flight, and the barriers become free.
+template <bool STAGE, int ADAM, int BT>
+__global__ __launch_bounds__(BT) void k_preprocess_bwd(
     int P, int deg, int sh_stride, const float* __restrict__ means3D, const float* __restrict__ dc,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
@@ -608,10 +616,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float* __restrict__ dL_dcov3D, float* __restrict__ st_accum, float* __restrict__ st_denom,
     float* __restrict__ st_max_radii, const GsrAdamArgs A) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
-  __shared__ int32_t need_sh[256];
+  __shared__ int32_t need_sh[BT];
   const int S = 3 * sh_stride, Sp = S | 1;
-  const size_t row0 = (size_t)blockIdx.x * 256;
-  const int rows = (int)min((size_t)256, (size_t)P - row0);
+  const size_t row0 = (size_t)blockIdx.x * BT;
+  const int rows = (int)min((size_t)BT, (size_t)P - row0);
   if (STAGE) {
     // rows to fetch: those with instances (their coefficients enter the gradient); with the optimizer folded in, every
     // row that will be UPDATED (all of them / the visible ones), since the update reads the parameter from the staged copy
@@ -621,12 +629,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     else
     need_sh[threadIdx.x] = (int)threadIdx.x < rows ? (int32_t)min(tiles_touched[row0 + threadIdx.x], 1u) : 0;
     __syncthreads();
-    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds, need_sh);   // only the rows of Gaussians with instances are read below
+    stage_rows_in<BT>(shs + row0 * S, rows * S, S, Sp, sh_lds, need_sh);   // only the rows of Gaussians with instances are read below
     __syncthreads();
   }
   float* my_row = sh_lds + threadIdx.x * Sp;
-  const bool active = blockIdx.x * 256 + threadIdx.x < P;
-  const int idx = active ? blockIdx.x * 256 + threadIdx.x : P - 1;   // idle tail threads mirror the last Gaussian (no stores)
+  const bool active = blockIdx.x * BT + threadIdx.x < P;
+  const int idx = active ? blockIdx.x * BT + threadIdx.x : P - 1;   // idle tail threads mirror the last Gaussian (no stores)
   const int K = (deg + 1) * (deg + 1);
   // A Gaussian that reached no tile (culled, or its alpha >= 1/255 ellipse misses every tile centre row) has no gradient
   // records: all its gradients are exact zeros, written below without touching its inputs.
@@ -915,14 +923,14 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       // f_rest: dL/dsh[k][c] = basis_k * dL/drgb_c is rank one, so a row's gradient is 19 numbers (basis values, masked
       // dL/drgb) kept in LDS next to the staged PARAMETER rows; the update then runs over the block's span of f_rest as flat
       // 16-B pieces (coalesced m / v / p traffic), forming each element's gradient on the fly.
-      float* fac = sh_lds + 256 * Sp + threadIdx.x * 19;
+      float* fac = sh_lds + BT * Sp + threadIdx.x * 19;
 #pragma unroll
       for (int k = 0; k < 16; k++) fac[k] = (have_sh && k < K) ? bs[k] : 0.f;
       fac[16] = g_col[0]; fac[17] = g_col[1]; fac[18] = g_col[2];
       __syncthreads();
-      const float* facs = sh_lds + 256 * Sp;
+      const float* facs = sh_lds + BT * Sp;
       const int nflt = rows * S, n4 = nflt >> 2;
-      const int dr = 1024 / S, dcol = 1024 - dr * S;
+      const int dr = (4 * BT) / S, dcol = (4 * BT) - dr * S;
       int r = (threadIdx.x * 4) / S, c = threadIdx.x * 4 - r * S;
       float* Pg = A.p[2] + row0 * S;
       float* Mg = A.m[2] + row0 * S;
@@ -934,13 +942,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         gsr_f4 mq[AHEAD + 1], vq[AHEAD + 1];
 #pragma unroll
         for (int u = 0; u < AHEAD; u++) {
-          const int iu = threadIdx.x + 256 * u;
+          const int iu = threadIdx.x + BT * u;
           if (iu < n4) { mq[u] = gsr_ld_stream(Mg + 4 * (size_t)iu); vq[u] = gsr_ld_stream(Vg + 4 * (size_t)iu); }
         }
-        for (int i = threadIdx.x; i < n4; i += 256) {
-          if (i + 256 * AHEAD < n4) {
-            mq[AHEAD] = gsr_ld_stream(Mg + 4 * (size_t)(i + 256 * AHEAD));
-            vq[AHEAD] = gsr_ld_stream(Vg + 4 * (size_t)(i + 256 * AHEAD));
+        for (int i = threadIdx.x; i < n4; i += BT) {
+          if (i + BT * AHEAD < n4) {
+            mq[AHEAD] = gsr_ld_stream(Mg + 4 * (size_t)(i + BT * AHEAD));
+            vq[AHEAD] = gsr_ld_stream(Vg + 4 * (size_t)(i + BT * AHEAD));
           }
           float pp[4], mm[4] = {mq[0].x, mq[0].y, mq[0].z, mq[0].w}, vv[4] = {vq[0].x, vq[0].y, vq[0].z, vq[0].w};
           int rr = r, cc = c;
@@ -970,7 +978,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
           int r1 = r, c1 = c;
 #pragma unroll
           for (int u = 0; u < GSR_STAGE_MAX_TRIPS; u++) {
-            const int i = threadIdx.x + 256 * u;
+            const int i = threadIdx.x + BT * u;
             want[u] = i < n4 && (need_sh[r1] > 0 || need_sh[min(r1 + (c1 + 3 >= S ? 1 : 0), rows - 1)] > 0);
             if (want[u]) { mq[u] = gsr_ld_stream(Mg + 4 * (size_t)i); vq[u] = gsr_ld_stream(Vg + 4 * (size_t)i); }
             r1 += dr; c1 += dcol;
@@ -979,7 +987,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         }
 #pragma unroll
         for (int u = 0; u < GSR_STAGE_MAX_TRIPS; u++) {
-          const int i = threadIdx.x + 256 * u;
+          const int i = threadIdx.x + BT * u;
           if (want[u]) {                          // (else: a piece of invisible rows only, neither read nor written)
             const gsr_f4 m4 = mq[u], v4 = vq[u];
             float pp[4], mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -1020,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
           if (c >= S) { c -= S; r++; }
         }
       }
-      for (int e = n4 * 4 + threadIdx.x; e < nflt; e += 256) {   // tail of a span whose length is not a multiple of 4
+      for (int e = n4 * 4 + threadIdx.x; e < nflt; e += BT) {   // tail of a span whose length is not a multiple of 4
         const int r2 = e / S, c2 = e - r2 * S;
         if (need_sh[r2] > 0) {
           const int kk = c2 / 3, ch = c2 - 3 * kk;
@@ -1071,7 +1079,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         }
       }
       __syncthreads();
-      stage_rows_out(dL_dshs + row0 * S, rows * S, S, Sp, sh_lds);
+      stage_rows_out<BT>(dL_dshs + row0 * S, rows * S, S, Sp, sh_lds);
     } else if (active) {
       for (int k = 0; k < stored; k++) {
         const float bk = (have_sh && k < K) ? bs[k] : 0.f;
@@ -1225,7 +1233,7 @@ int gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, con
     stage = g->shs != nullptr;
     if (stage && !can_stage_sh(s, g, &lds)) return -1;     // (f_rest rows are updated from their staged copy)
     if (!stage && g->sh_coeffs != 0) return -1;
-    if (stage) lds += (size_t)256 * 19 * sizeof(float);
+    if (stage) lds = (lds / 256) * GSR_BWD_ADAM_BT + (size_t)GSR_BWD_ADAM_BT * 19 * sizeof(float);   // rows of this kernel's workgroup
     A = *adam;
   } else {
     stage = can_stage_sh(s, g, &lds) && gr->dL_dshs && (((uintptr_t)gr->dL_dshs & 15) == 0);
@@ -1238,22 +1246,22 @@ int gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, con
       (const uint32_t*)(geom + L.meta) + 2, cap, gr->dL_dmeans3D,                                                      \
       gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities, gr->dL_dscales, gr->dL_drotations, \
       gr->dL_dcov3D, gr->xyz_gradient_accum, gr->denom, gr->max_radii2D, A
-#define GSR_PRE_BWD(ST, AD)                                                                                            \
+#define GSR_PRE_BWD(ST, AD, BT_)                                                                                       \
   do {                                                                                                                 \
     if (lds > 48 * 1024)                                                                                               \
-      (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<ST, AD>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                (int)lds);                                                                             \
-    GSR_LAUNCH(AD ? "preprocess_bwd_adam" : "preprocess_bwd", (k_preprocess_bwd<ST, AD>), dim3((P + 255) / 256),       \
-               dim3(256), ST ? lds : 0, st, GSR_PRE_BWD_ARGS);                                                         \
+      (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<ST, AD, BT_>,                                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+    GSR_LAUNCH(AD ? "preprocess_bwd_adam" : "preprocess_bwd", (k_preprocess_bwd<ST, AD, BT_>),                         \
+               dim3((P + BT_ - 1) / BT_), dim3(BT_), ST ? lds : 0, st, GSR_PRE_BWD_ARGS);                              \
   } while (0)
   if (!adam) {
-    if (stage) GSR_PRE_BWD(true, 0); else GSR_PRE_BWD(false, 0);
+    if (stage) GSR_PRE_BWD(true, 0, 256); else GSR_PRE_BWD(false, 0, 256);
   } else if (adam_mode == 2) {
-    if (stage) GSR_PRE_BWD(true, 2); else GSR_PRE_BWD(false, 2);
+    if (stage) GSR_PRE_BWD(true, 2, GSR_BWD_ADAM_BT); else GSR_PRE_BWD(false, 2, 256);
   } else if (adam_mode == 3) {
-    if (stage) GSR_PRE_BWD(true, 3); else GSR_PRE_BWD(false, 3);
+    if (stage) GSR_PRE_BWD(true, 3, GSR_BWD_ADAM_BT); else GSR_PRE_BWD(false, 3, 256);
   } else {
-    if (stage) GSR_PRE_BWD(true, 1); else GSR_PRE_BWD(false, 1);
+    if (stage) GSR_PRE_BWD(true, 1, GSR_BWD_ADAM_BT); else GSR_PRE_BWD(false, 1, 256);
   }
 #undef GSR_PRE_BWD
 #undef GSR_PRE_BWD_ARGS
