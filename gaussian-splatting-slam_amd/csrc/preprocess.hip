@@ -595,6 +595,9 @@ __device__ __forceinline__ void adam_row(const GsrAdamArgs& A, const int grp, co
 #ifndef GSR_BWD_ADAM_BT
 #define GSR_BWD_ADAM_BT 64    // Gaussians per workgroup of the folded-optimizer backward with staged SH rows (256 / 128 / 64: 0.351 / 0.347 / 0.337 ms at C3)
 #endif
+#ifndef GSR_BWD_PLAIN_BT
+#define GSR_BWD_PLAIN_BT 64   // ... of the plain backward (gradients stored; what the multi-GPU schedules run): 256 / 128 / 64 -> 0.158 / 0.151 / 0.148 ms
+#endif
 #ifndef GSR_ADAM_AHEAD
 #define GSR_ADAM_AHEAD 6      // trips of f_rest moments in flight ahead of the one being updated (2 -> 6: -2 % of the kernel)
 #endif
@@ -1237,6 +1240,7 @@ int gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, con
     A = *adam;
   } else {
     stage = can_stage_sh(s, g, &lds) && gr->dL_dshs && (((uintptr_t)gr->dL_dshs & 15) == 0);
+    if (stage) lds = (lds / 256) * GSR_BWD_PLAIN_BT;
   }
 #define GSR_PRE_BWD_ARGS                                                                                              \
   P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, g->colors_precomp, g->opacities, g->scales, g->rotations, \
@@ -1255,7 +1259,7 @@ int gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, con
                dim3((P + BT_ - 1) / BT_), dim3(BT_), ST ? lds : 0, st, GSR_PRE_BWD_ARGS);                              \
   } while (0)
   if (!adam) {
-    if (stage) GSR_PRE_BWD(true, 0, 256); else GSR_PRE_BWD(false, 0, 256);
+    if (stage) GSR_PRE_BWD(true, 0, GSR_BWD_PLAIN_BT); else GSR_PRE_BWD(false, 0, 256);
   } else if (adam_mode == 2) {
     if (stage) GSR_PRE_BWD(true, 2, GSR_BWD_ADAM_BT); else GSR_PRE_BWD(false, 2, 256);
   } else if (adam_mode == 3) {
