@@ -16,7 +16,7 @@
 void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool,
                                bool, hipStream_t);
 void gsr_launch_scan_block_sums(int, char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
-void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, hipStream_t);
+void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, bool, hipStream_t);
 void gsr_launch_adam_culled_rows(int, int, const char*, const GsrGeomLayout&, const GsrAdamArgs&, hipStream_t);
 int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
                               const GsrGeomLayout&, const float4*, uint32_t, const gsr_grads*, const GsrAdamArgs*, int,
@@ -281,7 +281,7 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   if (shade_aside && !tile_local) {
     if ((rc = gsr_check(hipEventRecord(shade_aside->fork, st), "fork shade"))) return rc;
     if ((rc = gsr_check(hipStreamWaitEvent(shade_aside->stream, shade_aside->fork, 0), "fork shade"))) return rc;
-    gsr_launch_shade(s, g, geom, L, shade_aside->stream);
+    gsr_launch_shade(s, g, geom, L, /*beside_other_work=*/true, shade_aside->stream);
     if ((rc = gsr_check(hipEventRecord(shade_aside->join, shade_aside->stream), "join shade"))) return rc;
   }
 
@@ -357,7 +357,7 @@ int gsr_forward_shade(const gsr_settings* s, const gsr_gaussians* g, void* geome
   if (rc) return rc;
   if (g->P == 0) return 0;
   const GsrGeomLayout L = gsr_geom_layout(g->P);
-  gsr_launch_shade(s, g, (char*)geometry_state, L, (hipStream_t)stream);
+  gsr_launch_shade(s, g, (char*)geometry_state, L, false, (hipStream_t)stream);
   if ((rc = debug_sync(s, (hipStream_t)stream, "shade"))) return rc;
   return gsr_launch_status("shade");
 }
@@ -401,7 +401,7 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
       if (a && sh_ready == a->join) {      // colour pass on the side stream, beside the tile sort (see forward_geometry)
         if ((rc = gsr_check(hipEventRecord(a->fork, st), "fork shade"))) return rc;
         if ((rc = gsr_check(hipStreamWaitEvent(a->stream, a->fork, 0), "fork shade"))) return rc;
-        gsr_launch_shade(s, g, (char*)geom, GL, a->stream);
+        gsr_launch_shade(s, g, (char*)geom, GL, /*beside_other_work=*/true, a->stream);
         if ((rc = gsr_check(hipEventRecord(a->join, a->stream), "join shade"))) return rc;
       }
     }
@@ -450,7 +450,7 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
     // the colours are the LAST thing the compositing needs: everything above ran without the SH coefficients, which may
     // still be receiving their update on another stream
     if (sh_ready && (rc = gsr_check(hipStreamWaitEvent(st, sh_ready, 0), "wait for the SH coefficients"))) return rc;
-    gsr_launch_shade(s, g, geom, GL, st);
+    gsr_launch_shade(s, g, geom, GL, false, st);
     if ((rc = debug_sync(s, st, "shade"))) return rc;
   }
   gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),

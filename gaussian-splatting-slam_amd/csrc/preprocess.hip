@@ -519,22 +519,22 @@ void gsr_launch_sum_tiles(int P, const char* geom, const GsrGeomLayout& L, uint3
 // tile sort - their all-reduce + Adam update can still be in flight on another stream while those geometry stages of the
 // next step run.  Same arithmetic as the fused K1 path (bitwise identical colours).
 // ---------------------------------------------------------------------------------------------------
-template <bool STAGE>
-__global__ __launch_bounds__(256) void k_shade(int P, int deg, int sh_stride, const float* __restrict__ means3D,
+template <bool STAGE, int BT>
+__global__ __launch_bounds__(BT) void k_shade(int P, int deg, int sh_stride, const float* __restrict__ means3D,
                                                const float* __restrict__ dc, const float* __restrict__ shs,
                                                const float* __restrict__ campos,
                                                const uint32_t* __restrict__ tiles_touched, float4* __restrict__ rec,
                                                uint8_t* __restrict__ clamped) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
-  __shared__ int32_t need_sh[256];
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  __shared__ int32_t need_sh[BT];
+  const int idx = blockIdx.x * BT + threadIdx.x;
   const int S = 3 * sh_stride, Sp = S | 1;
   if (STAGE) {
-    const size_t row0 = (size_t)blockIdx.x * 256;
-    const int rows = (int)min((size_t)256, (size_t)P - row0);
+    const size_t row0 = (size_t)blockIdx.x * BT;
+    const int rows = (int)min((size_t)BT, (size_t)P - row0);
     need_sh[threadIdx.x] = (int)threadIdx.x < rows ? (int32_t)min(tiles_touched[row0 + threadIdx.x], 1u) : 0;
     __syncthreads();
-    stage_rows_in(shs + row0 * S, rows * S, S, Sp, sh_lds, need_sh);
+    stage_rows_in<BT>(shs + row0 * S, rows * S, S, Sp, sh_lds, need_sh);
     __syncthreads();
   }
   if (idx >= P || tiles_touched[idx] == 0) return;
@@ -592,6 +592,9 @@ __device__ __forceinline__ void adam_row(const GsrAdamArgs& A, const int grp, co
   for (int j = 0; j < N; j++) { P[j] = p[j]; M[j] = m[j]; V[j] = v[j]; }
 }
 
+#ifndef GSR_SHADE_BT
+#define GSR_SHADE_BT 64
+#endif
 #ifndef GSR_BWD_ADAM_BT
 #define GSR_BWD_ADAM_BT 64    // Gaussians per workgroup of the folded-optimizer backward with staged SH rows (256 / 128 / 64: 0.351 / 0.347 / 0.337 ms at C3)
 #endif
@@ -1183,7 +1186,13 @@ static bool can_stage_sh(const gsr_settings* s, const gsr_gaussians* g, size_t* 
   return true;
 }
 
-void gsr_launch_shade(const gsr_settings* s, const gsr_gaussians* g, char* geom, const GsrGeomLayout& L, hipStream_t st) {
+// beside_other_work: the pass runs on a side stream next to the (latency-bound) tile sort.  There the 256-row form is kept on
+// purpose: 64-row workgroups finish the pass in 0.065 instead of 0.096 ms at C3 but take so much more of the machine while they
+// run that the radix passes beside them slow down by more (step 1.408 vs 1.390 ms; throttling the pass further - two or one
+// workgroup per CU through an LDS pad - gains nothing / costs 0.04 ms).  On the caller's own stream - blocking
+// forward, late colour pass of the data-parallel overlap, forward-only renders - the pass is on the critical path and gets 64.
+void gsr_launch_shade(const gsr_settings* s, const gsr_gaussians* g, char* geom, const GsrGeomLayout& L, bool beside_other_work,
+                      hipStream_t st) {
   const int P = g->P;
   if (P == 0 || g->colors_precomp) return;
   size_t lds = 0;
@@ -1191,10 +1200,14 @@ void gsr_launch_shade(const gsr_settings* s, const gsr_gaussians* g, char* geom,
 #define GSR_SHADE_ARGS                                                                                           \
   P, s->sh_degree, g->sh_coeffs, g->means3D, g->dc, g->shs, s->campos, (const uint32_t*)(geom + L.tiles_touched), \
       (float4*)(geom + L.rec), (uint8_t*)(geom + L.clamped)
-  if (stage)
-    GSR_LAUNCH("shade", k_shade<true>, dim3((P + 255) / 256), dim3(256), lds, st, GSR_SHADE_ARGS);
+  // (rows per workgroup: 64, as in the backward - 12 KB of staged rows instead of 46 KB, 13 workgroups per CU instead of 3)
+  if (stage && beside_other_work)
+    GSR_LAUNCH("shade", (k_shade<true, 256>), dim3((P + 255) / 256), dim3(256), lds, st, GSR_SHADE_ARGS);
+  else if (stage)
+    GSR_LAUNCH("shade", (k_shade<true, GSR_SHADE_BT>), dim3((P + GSR_SHADE_BT - 1) / GSR_SHADE_BT), dim3(GSR_SHADE_BT),
+               (lds / 256) * GSR_SHADE_BT, st, GSR_SHADE_ARGS);
   else
-    GSR_LAUNCH("shade", k_shade<false>, dim3((P + 255) / 256), dim3(256), 0, st, GSR_SHADE_ARGS);
+    GSR_LAUNCH("shade", (k_shade<false, 256>), dim3((P + 255) / 256), dim3(256), 0, st, GSR_SHADE_ARGS);
 #undef GSR_SHADE_ARGS
 }
 
