@@ -138,17 +138,19 @@ def test_lowlevel_async_call_matches_blocking_state(tlo, pinned):
 def test_parity_suite_with_the_other_backward_form_and_blocking_forward():
     """The two forms of the compositing backward (one wave per tile from 6000 tiles up, four waves per tile below) are chosen by
     image size, so the small-image parity tests only ever see the four-wave form.  Re-run the core parity tests in a child
-    process with GSR_BWD_FORM=tile (every mode: SH / dc / colours x AA x cov3D_precomp, edge cases, bitwise repeat), and once
+    process with GSR_BWD_FORM=tile (two parity modes, edge cases, bitwise repeat, committed golden), and once
     more with the blocking forward (GSR_FORWARD_MODE=sync) and the colour pass kept on the caller's stream."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sel = ["tests/test_parity_gpu.py::test_forward_backward_parity", "tests/test_parity_gpu.py::test_edge_cases",
-           "tests/test_parity_gpu.py::test_bitwise_reproducible", "tests/test_parity_gpu.py::test_against_committed_golden",
-           "tests/test_parity_gpu.py::test_config4_code_path_small"]
+    # (two of the six parity modes per child - SH with anti-aliasing, precomputed colours with anti-aliasing and cov3D_precomp -
+    # keep the children at ~30 s each: the float64 oracle is what takes the time)
+    par = "tests/test_parity_gpu.py::test_forward_backward_parity"
+    sel = [par + "[sh-True-False]", par + "[colors-True-True]", "tests/test_parity_gpu.py::test_edge_cases",
+           "tests/test_parity_gpu.py::test_bitwise_reproducible", "tests/test_parity_gpu.py::test_against_committed_golden"]
     for extra, tests in (({"GSR_BWD_FORM": "tile", "GSR_TLO_SETTLE": "0"}, sel),      # + tile-local binning from frame 2 on
-                         ({"GSR_BWD_FORM": "quad", "GSR_FORWARD_MODE": "sync", "GSR_SHADE_STREAM": "1"}, sel[:3])):
+                         ({"GSR_BWD_FORM": "quad", "GSR_FORWARD_MODE": "sync", "GSR_SHADE_STREAM": "1"}, sel[1:4])):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + tests, cwd=root, env=env,
                            capture_output=True, text=True, timeout=900)
