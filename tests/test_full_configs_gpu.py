@@ -57,7 +57,23 @@ def _check_sampled(ref, out, mask, W, H, depth=True, ref32=None):
         assert rel_l2(out["grads"][k], g_ref) <= GRAD_REL, (k, rel_l2(out["grads"][k], g_ref))
 
 
-def test_config3_full_size_forward_backward_vs_oracle_tiles():
+def _tile_local_frame_equals(out, run, monkeypatch):
+    """The same frame through the tile-local binning form (no global depth sort; normally entered once a shape's capacity has
+    held for three frames): bit-identical images and gradients at full size."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _workspace as ws
+    if ws._BINNING != "tile":
+        return
+    monkeypatch.setattr(ws, "TLO_SETTLE_FRAMES", 0)
+    n0 = dgr.call_stats().get("tile_local_frames", 0)
+    again = run()
+    assert dgr.call_stats().get("tile_local_frames", 0) == n0 + 1
+    assert torch.equal(out["color"], again["color"]) and torch.equal(out["invdepth"], again["invdepth"])
+    for k in out["grads"]:
+        assert torch.equal(out["grads"][k], again["grads"][k]), k
+
+
+def test_config3_full_size_forward_backward_vs_oracle_tiles(monkeypatch):
     raw, cams, c = make_config(3, views=4)
     cam, W, H = cams[1], c["W"], c["H"]
     assert raw.xyz.shape[0] == 1_000_000 and (W, H) == (1920, 1080)
@@ -73,9 +89,10 @@ def test_config3_full_size_forward_backward_vs_oracle_tiles():
     assert torch.equal(out["color"], out2["color"])
     for k in out["grads"]:
         assert torch.equal(out["grads"][k], out2["grads"][k]), k
+    _tile_local_frame_equals(out, lambda: run_hip(raw, cam, 3, bg, gc=gc, gd=gd), monkeypatch)
 
 
-def test_config4_full_size_properties_and_oracle_tiles():
+def test_config4_full_size_properties_and_oracle_tiles(monkeypatch):
     raw, cams, c = make_config(4, views=2)
     cam, W, H = cams[0], c["W"], c["H"]
     assert raw.xyz.shape[0] == 5_000_000 and (W, H) == (3840, 2160) and c["antialiasing"]
@@ -100,6 +117,7 @@ def test_config4_full_size_properties_and_oracle_tiles():
     assert torch.equal(a["color"], a2["color"]) and torch.equal(a["invdepth"], a2["invdepth"])
     for k in a["grads"]:
         assert torch.equal(a["grads"][k], a2["grads"][k]), k
+    _tile_local_frame_equals(a, lambda: run_hip(raw, cam, 3, bg, antialiasing=True, gc=gcf, gd=gdf), monkeypatch)
     del a, a2, b
     # state: background where nothing lands, transmittance in [0, 1], ranges tile [0, R) in order, lists sorted by
     # (tile, depth bits, id) with every id's tile inside its rect - checked exhaustively on the integer arrays
