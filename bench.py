@@ -28,6 +28,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # same guide, "Peak FP32 (vector)": what SURVEY.md 8(d)'s FLOP model of the compositing kernels is priced against
+# SURVEY.md 8(d) FLOP model: forward 20 FLOP per (pixel, Gaussian) pair evaluated + 8 per pair blended; backward 70 per pair replayed
+FWD_FLOP_PER_PAIR, FWD_FLOP_PER_BLEND, BWD_FLOP_PER_PAIR = 20, 8, 70
 # FP32 vector issue peak: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md
 # "Wave scheduling" and the cycle-constants row `v_fma_f32 (wave64) 2 cyc (SIMD-32)`), 2.4 GHz -> 1.2288e12 wave-instr/s
 # (= the 157.3 TFLOP/s fp32 vector peak / 128 flop per wave64 FMA).  profiles/r02_valu_microbench.txt measures it on the part.
@@ -252,7 +255,7 @@ def main():
                     help="hip: one-launch Adam kernel (torch.optim.Adam semantics, the reference's default optimizer); "
                          "hip_sparse: SparseGaussianAdam (reference train.py:173-176); *_fused: the same update folded into "
                          "the rasterizer's backward (gsr_backward_adam), bit-identical results")
-    ap.add_argument("--loss", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--loss", default="hip", choices=["hip"])
     ap.add_argument("--concat-sh", action="store_true",
                     help="pass torch.cat(dc, rest) as shs (separate_sh=False); default mirrors reference train.py:106 with "
                          "SparseGaussianAdam importable: separate_sh=True")
@@ -282,9 +285,25 @@ def main():
                     help="hip_fused: update the rows without tile instances on a side stream beside the compositing backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
-    ap.add_argument("--forward-mode", default=None, choices=["async", "sync"],
-                    help="rasterizer forward: non-blocking with device-side num_rendered (default) or the blocking read-back")
+    ap.add_argument("--forward-mode", default=None, choices=["exact", "async", "sync"],
+                    help="rasterizer forward: exact (default: the frame is enqueued whole for a capacity estimate, its count is "
+                         "verified before the call returns and phase 2 repeated if the estimate did not hold - every frame "
+                         "exact), async (no wait at all: a truncated frame's backward is a no-op and the Trainer runs the view "
+                         "again) or sync (the published blocking read-back in the middle of the forward)")
     args = ap.parse_args()
+    if args.config == 5 and not args.densify and os.environ.get("BENCH_C5_STATIC") != "1":
+        # BASELINE configs[4] "SLAM-style incremental: 50k -> 500k growing Gaussians, per-frame 720p fwd+bwd, densify/prune every
+        # 100 iters": the reference's schedule (train.py:155-168, arguments/__init__.py:84-90) from iteration 100; its 0.0002
+        # gradient threshold stops the SYNTHETIC scene near 100 k, so the preset uses 0.00002 and stops at 500 k
+        args.densify = True
+        if "--densify-from" not in sys.argv:
+            args.densify_from = 100
+        if "--densify-grad-threshold" not in sys.argv:
+            args.densify_grad_threshold = 0.00002
+        if args.densify_max is None:
+            args.densify_max = 500000
+        if "--steps" not in sys.argv:
+            args.steps = 2500
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one process per
     # GPU) BEFORE anything in this process touches the GPU, relay the child's stdout / exit code.
@@ -396,8 +415,10 @@ def main():
         "host_ms_per_step_median": pct(host_ms, 0.5), "host_ms_per_step_p90": pct(host_ms, 0.9),
         "device_allocs_in_timed_region": int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - alloc0),
         # frames of the whole run (warm-up included) by forward form; tile_local_frames_timed of the K*views timed frames
-        "forward_mode": {"mode": dgr.forward_mode(), "async_frames": timed_stats["async_frames"],
-                         "sync_frames": timed_stats["sync_frames"], "overflow_frames": timed_stats["overflow_frames"],
+        "forward_mode": {"mode": dgr.forward_mode(), "exact_frames": timed_stats["exact_frames"],
+                         "async_frames": timed_stats["async_frames"], "sync_frames": timed_stats["sync_frames"],
+                         "rerendered_frames": timed_stats["rerendered_frames"],
+                         "overflow_frames": timed_stats["overflow_frames"], "rerun_views": trainer.rerun_views,
                          "tile_local_frames": timed_stats.get("tile_local_frames", 0),
                          "tile_local_frames_timed": timed_stats.get("tile_local_frames", 0)
                                                     - stats_before.get("tile_local_frames", 0)},
@@ -463,25 +484,40 @@ def main():
             result["pair_evaluations"] = pe
         except Exception as e:   # an extra; never lose the headline to it
             result["pair_evaluations"] = {"error": repr(e)}
+        # FLOP model of the two compositing kernels (pairs are counted on view 0, durations are the profiled average)
+        pe = result.get("pair_evaluations", {})
+        flops = {}
+        if "fwd_pairs" in pe:
+            flops["render_fwd"] = FWD_FLOP_PER_PAIR * pe["fwd_pairs"] + FWD_FLOP_PER_BLEND * pe.get("fwd_blended", 0)
+            flops["render_bwd"] = BWD_FLOP_PER_PAIR * pe["bwd_pairs"]
+        cfg_key = f"c{args.config}:{P}:{W}x{H}"
+
+        def roof_of(name):
+            d = kt[name]
+            traffic = pmc_traffic(name, cfg_key)
+            hbm = {"achieved": d["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBS, 5),
+                   "alg_bytes": d["alg_bytes"], "traffic": traffic,
+                   "traffic_ratio": round(traffic / d["alg_bytes"], 3) if traffic else None}
+            valu = pmc_valu(name, d["avg_ms"], cfg_key)      # issue utilisation (SQ_INSTS_VALU of the committed PMC pass): NOT a roofline fraction
+            roof = {"kernel": name, "avg_ms": d["avg_ms"]}
+            if name in flops:
+                # compositing kernels: records staged through LDS, few bytes moved - priced by SURVEY 8(d)'s FLOP model against
+                # the FP32 vector peak; the HBM view and the VALU issue utilisation ride along
+                tf = flops[name] / (d["avg_ms"] * 1e-3) / 1e12
+                roof.update({"bound": "valu", "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tf / FP32_PEAK_TFLOPS, 4), "flop_model": flops[name], "traffic": traffic,
+                             "traffic_ratio": hbm["traffic_ratio"], "hbm": hbm, "valu_issue": valu})
+            else:
+                roof.update({"bound": "hbm", **hbm})
+            return roof
         named = {k: v for k, v in kt.items() if "alg_bytes" in v}
         if named:
             dom = max(named, key=lambda k: named[k]["avg_ms"] * named[k]["calls"])
-            d = named[dom]
-            cfg_key = f"c{args.config}:{P}:{W}x{H}"
-            hbm = {"achieved": d["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBS, 5),
-                   "alg_bytes": d["alg_bytes"], "traffic": pmc_traffic(dom, cfg_key)}
-            valu = pmc_valu(dom, d["avg_ms"], cfg_key)
-            roof = {"kernel": dom, "avg_ms": d["avg_ms"]}
-            if dom in ("render_fwd", "render_bwd") and valu is not None:
-                # the compositing kernels stage their records through LDS and move few bytes: what bounds them is FP32
-                # VALU issue.  achieved = wave64 VALU instructions per second (SQ_INSTS_VALU of the committed PMC pass of
-                # this workload / the live HIP-event duration), peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per instruction.
-                roof.update({"bound": "valu", "achieved": round(valu["insts_per_launch"] / (d["avg_ms"] * 1e-3) / 1e9, 1),
-                             "peak": round(VALU_WAVE_INSTR_PER_S / 1e9, 1), "unit": "G wave64-VALU-instr/s",
-                             "frac": valu["issue_frac"], "traffic": hbm["traffic"], "valu": valu, "hbm": hbm})
-            else:
-                roof.update({"bound": "hbm", **hbm, "valu": valu})
-            result["roofline"] = roof
+            result["roofline"] = roof_of(dom)
+            # the other kernels above 5 % of the step, same pricing, for the record
+            total = sum(v["avg_ms"] * v["calls"] for v in kt.values())
+            result["rooflines"] = {k: {kk: vv for kk, vv in roof_of(k).items() if kk in ("bound", "achieved", "peak", "unit", "frac", "traffic_ratio")}
+                                   for k in named if k != dom and named[k]["avg_ms"] * named[k]["calls"] > 0.05 * total}
 
     log("extras done; cpu baseline next")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -15,9 +15,9 @@
 // launchers defined in the kernel files
 void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool,
                                bool, hipStream_t);
-void gsr_launch_scan_block_sums(int, char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
+void gsr_launch_scan_block_sums(int, char*, const GsrGeomLayout&, uint32_t*, unsigned long long*, hipStream_t);
 void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, bool, hipStream_t);
-void gsr_launch_adam_culled_rows(int, int, const char*, const GsrGeomLayout&, const GsrAdamArgs&, hipStream_t);
+void gsr_launch_adam_culled_rows(int, int, const char*, const GsrGeomLayout&, const GsrAdamArgs&, uint32_t, hipStream_t);
 int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
                               const GsrGeomLayout&, const float4*, uint32_t, const gsr_grads*, const GsrAdamArgs*, int,
                               hipStream_t);
@@ -33,7 +33,7 @@ void gsr_launch_count_pairs(const gsr_settings*, int, int, const uint2*, const u
                             hipStream_t);
 void gsr_launch_render_bwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*,
                            const float*, const uint32_t*, const float*, const float*, const uint32_t*, float4*,
-                           hipStream_t);
+                           const uint32_t*, uint32_t, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------
 // errors
@@ -145,20 +145,42 @@ void gsr_prof_end(hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pinned read-back slot (one per host thread)
+// Per host thread AND per device: the pinned read-back slot, its event, and the side stream of the colour pass.  Created on first
+// use with that device current (one process per GPU is the design, but one thread driving two devices gets two sets: a stream or
+// an event made on device 0 is never handed to a launch on device 1).
 // ---------------------------------------------------------------------------------------------------
+struct SideShade { hipStream_t stream; hipEvent_t fork, join; bool ok, tried; };
+struct DeviceLocal {
+  uint32_t* pinned = nullptr;        // 64 B of pinned host memory: [0..3] the blocking path's copy of meta[0..3]; [8..9] the early count
+  uint32_t* pinned_dev = nullptr;    // the same allocation as the device sees it
+  hipEvent_t readback = nullptr;
+  SideShade shade = {nullptr, nullptr, nullptr, false, false};
+};
+static DeviceLocal* device_local() {
+  static thread_local std::map<int, DeviceLocal> per_device;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  return &per_device[dev];
+}
+
 static uint32_t* pinned_slot() {
-  static thread_local uint32_t* p = nullptr;
-  if (!p) {
-    if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+  DeviceLocal* d = device_local();
+  if (!d) return nullptr;
+  if (!d->pinned) {
+    if (hipHostMalloc((void**)&d->pinned, 64, hipHostMallocDefault) != hipSuccess) { d->pinned = nullptr; return nullptr; }
+    memset(d->pinned, 0, 64);
+    void* alias = nullptr;
+    if (hipHostGetDevicePointer(&alias, d->pinned, 0) == hipSuccess) d->pinned_dev = (uint32_t*)alias;
+    else (void)hipGetLastError();
   }
-  return p;
+  return d->pinned;
 }
 
 static hipEvent_t readback_event() {
-  static thread_local hipEvent_t ev = nullptr;
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
-  return ev;
+  DeviceLocal* d = device_local();
+  if (!d) return nullptr;
+  if (!d->readback && hipEventCreateWithFlags(&d->readback, hipEventDisableTiming) != hipSuccess) d->readback = nullptr;
+  return d->readback;
 }
 
 static int tile_bits(int tiles) {
@@ -231,12 +253,12 @@ size_t gsr_backward_scratch_bytes(int32_t P, int64_t R) {
 // scan / emission / tile sort, which are latency-bound and leave most of the machine idle.  Used by gsr_forward_async from
 // 200 k Gaussians up (below that the extra launch and two event operations cost the host more than the overlap saves);
 // GSR_SHADE_STREAM=0 keeps everything on the caller's stream, =1 forces the side stream at any size.  Same results.
-struct SideShade { hipStream_t stream; hipEvent_t fork, join; bool ok; };
 static SideShade* side_shade() {
-  static thread_local SideShade ss = {nullptr, nullptr, nullptr, false};
-  static thread_local bool tried = false;
-  if (!tried) {
-    tried = true;
+  DeviceLocal* d = device_local();
+  if (!d) return nullptr;
+  SideShade& ss = d->shade;
+  if (!ss.tried) {
+    ss.tried = true;
     ss.ok = hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
@@ -259,7 +281,7 @@ static uint32_t* device_alias_of_pinned(uint32_t* host) {
 static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
                             int32_t* radii, hipStream_t st, bool defer_color, uint32_t* host_status,
                             hipEvent_t copied /* recorded right behind the status copy, or nullptr */,
-                            SideShade* shade_aside = nullptr, bool tile_local = false) {
+                            SideShade* shade_aside = nullptr, bool tile_local = false, bool* early_word = nullptr) {
   const int P = g->P;
   const GsrGeomLayout L = gsr_geom_layout(P);
   if (!geometry_state || geometry_bytes < L.total) {
@@ -292,7 +314,21 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
     // second form of the binning stage (binning.hip, k_tile_depth_sort): no global depth order; the instances are emitted in
     // index order, so the projection kernel has left per-workgroup instance totals: one single-workgroup scan gives the start
     // slots and num_rendered, and k_emit_instances finishes the prefix sum itself
-    gsr_launch_scan_block_sums(P, geom, L, meta, st);
+    // (a caller that waits for the count - forward_prepare_impl, gsr_forward_async(num_rendered_out) - gets it from the scan
+    // kernel itself: one 8-byte store into this thread's pinned slot, word pair [8..9], GSR_COUNT_VALID | flag << 62 | count)
+    unsigned long long* early = nullptr;
+    if (host_status) {
+      DeviceLocal* d = device_local();
+      if (d && d->pinned == host_status && d->pinned_dev) {
+        ((volatile unsigned long long*)(host_status + 8))[0] = 0ull;
+        early = (unsigned long long*)(d->pinned_dev + 8);
+      }
+    }
+    if (early_word) *early_word = early != nullptr;
+    gsr_launch_scan_block_sums(P, geom, L, meta, early, st);
+    if (host_status && !early &&
+        (rc = gsr_check(hipMemcpyAsync(host_status, meta, 16, hipMemcpyDeviceToHost, st), "read num_rendered")))
+      return rc;
     if (copied && (rc = gsr_check(hipEventRecord(copied, st), "record read-back event"))) return rc;
     return debug_sync(s, st, "tile-count scan");
   }
@@ -317,6 +353,38 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   return 0;
 }
 
+// Waits until the count of the forward just enqueued by THIS host thread has reached its pinned slot (`ev` was recorded right
+// behind the kernel / copy that delivers it - the rest of the forward may still be queued behind it) and decodes it.
+#define GSR_COUNT_VALID (1ull << 63)
+static int64_t wait_for_count(uint32_t* host, hipEvent_t ev, bool early_word) {
+  int rc;
+  if ((rc = gsr_check(hipEventSynchronize(ev), "wait for num_rendered"))) return rc;
+  unsigned long long total;
+  bool culled;
+  if (early_word) {
+    volatile unsigned long long* w = (volatile unsigned long long*)(host + 8);
+    unsigned long long v = *w;
+    // (the event completed behind the storing kernel, so the word is there; the bounded re-read only covers a write still
+    // travelling through the host bridge)
+    for (int spin = 0; !(v & GSR_COUNT_VALID) && spin < (1 << 22); spin++) v = *w;
+    if (!(v & GSR_COUNT_VALID)) { gsr_set_error("num_rendered did not arrive in the pinned slot"); return GSR_ERR_HIP; }
+    culled = (v >> 62) & 1ull;
+    total = v & ((1ull << 62) - 1ull);
+  } else {
+    total = (unsigned long long)host[2] | ((unsigned long long)host[3] << 32);
+    culled = host[1] & 1u;
+  }
+  if (culled) {
+    gsr_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+    return GSR_ERR_PREFILTERED_CULLED;
+  }
+  if (total > 0x3FFFFFFFull) {
+    gsr_set_error("num_rendered %llu does not fit 30 bits", total);
+    return GSR_ERR_TOO_MANY_INSTANCES;
+  }
+  return (int64_t)total;
+}
+
 static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
                                     size_t geometry_bytes, int32_t* radii, void* stream, bool defer_color) {
   int rc = validate(s, g);
@@ -328,18 +396,10 @@ static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* 
   if (!host || !ev) { gsr_set_error("hipHostMalloc / hipEventCreate failed"); return GSR_ERR_HIP; }
   // the host waits on an event recorded right behind the 16-byte copy, i.e. while the depth sort and the offset scan are still
   // queued: the GPU has ~0.1 ms of work left when the host goes on to size the binning state and enqueue the rest
-  if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, st, defer_color, host, ev))) return rc;
-  if ((rc = gsr_check(hipEventSynchronize(ev), "wait for num_rendered"))) return rc;
-  const unsigned long long total = (unsigned long long)host[2] | ((unsigned long long)host[3] << 32);
-  if (host[1] & 1u) {
-    gsr_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
-    return GSR_ERR_PREFILTERED_CULLED;
-  }
-  if (total > 0x3FFFFFFFull) {
-    gsr_set_error("num_rendered %llu does not fit 30 bits", total);
-    return GSR_ERR_TOO_MANY_INSTANCES;
-  }
-  return (int64_t)total;
+  bool early = false;
+  if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, st, defer_color, host, ev, nullptr, false, &early)))
+    return rc;
+  return wait_for_count(host, ev, early);
 }
 
 int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
@@ -480,31 +540,56 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
                       int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
                       size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
                       int32_t defer_color, void* sh_ready_event, uint32_t* host_status, int32_t tile_local_sort,
-                      void* stream) {
+                      void* stream, int64_t* num_rendered_out) {
   int rc = validate(s, g);
   if (rc) return rc;
   const bool tlo = tile_local_sort != 0;
+  if (num_rendered_out) *num_rendered_out = 0;
   if (g->P > 0) {
     const bool late = defer_color != 0 && !g->colors_precomp;
-    static const int aside_env = getenv("GSR_SHADE_STREAM") ? atoi(getenv("GSR_SHADE_STREAM")) : -1;
+    const char* aside_str = getenv("GSR_SHADE_STREAM");      // (read per call: tests switch it inside one process)
+    const int aside_env = aside_str ? atoi(aside_str) : -1;
     const bool want_aside = aside_env < 0 ? g->P >= 200000 : aside_env != 0;
     SideShade* aside = (want_aside && !late && !g->colors_precomp && (g->shs || g->dc) && !s->debug) ? side_shade() : nullptr;
-    if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late || aside != nullptr,
-                               nullptr, nullptr, aside, tlo)))
-      return rc;
-    // (the status words - flags, num_rendered and, in the tile-local form, the longest tile list meta[4] - leave at the END)
-    if (aside) {
-      rc = forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
-                               out_color, out_invdepth, for_backward != 0, false, aside->join, stream, tlo,
-                               host_status);
-      return rc;
+    // verified speculation (num_rendered_out): the count goes to this thread's pinned slot as EARLY as the kernels know it,
+    // the whole frame is enqueued for `capacity`, and only then does the host wait for the count - the device still has the
+    // binning and compositing stages queued, so it never idles while the host looks
+    uint32_t* host = nullptr;
+    hipEvent_t ev = nullptr;
+    bool early = false;
+    if (num_rendered_out) {
+      host = pinned_slot();
+      ev = readback_event();
+      if (!host || !ev) { gsr_set_error("hipHostMalloc / hipEventCreate failed"); return GSR_ERR_HIP; }
     }
-    return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
-                               out_color, out_invdepth, for_backward != 0, late, (hipEvent_t)sh_ready_event, stream, tlo,
-                               host_status);
+    if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late || aside != nullptr,
+                               host, ev, aside, tlo, &early)))
+      return rc;
+    // (the caller's status words - flags, num_rendered and, in the tile-local form, the longest tile list meta[4] - leave at the END)
+    rc = forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
+                             out_color, out_invdepth, for_backward != 0, aside ? false : late,
+                             aside ? aside->join : (hipEvent_t)sh_ready_event, stream, tlo, host_status);
+    if (rc) return rc;
+    if (num_rendered_out) {
+      const int64_t n = wait_for_count(host, ev, early);
+      if (n < 0) return (int)n;
+      *num_rendered_out = n;
+    }
+    return 0;
   }
   return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, 0, image_state, image_bytes, out_color,
                              out_invdepth, for_backward != 0, false, nullptr, stream);
+}
+
+int gsr_forward_rerender(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
+                         size_t binning_bytes, int64_t capacity, void* image_state, size_t image_bytes, float* out_color,
+                         float* out_invdepth, int32_t for_backward, int32_t tile_local_sort, uint32_t* host_status,
+                         void* stream) {
+  // everything phase 2 reads of the geometry state - records with their colours, tile counts, the count itself, depth order
+  // or per-workgroup start slots - was left complete by the gsr_forward_async call this one repairs
+  return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
+                             out_color, out_invdepth, for_backward != 0, false, nullptr, stream, tile_local_sort != 0,
+                             host_status);
 }
 
 static int adam_args(const gsr_gaussians* g, const gsr_fused_adam* opt, GsrAdamArgs& A) {
@@ -565,7 +650,8 @@ static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const in
     gsr_launch_render_bwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                           (const float4*)(geom + GL.rec), (const float*)(img + IL.final_T),
                           (const uint32_t*)(img + IL.n_contrib), dL_dcolor, dL_dinvdepth,
-                          (const uint32_t*)(bin + (tile_sort_result_buffer(tiles) ? BL.val_b : BL.val_a)), igrad, st);
+                          (const uint32_t*)(bin + (tile_sort_result_buffer(tiles) ? BL.val_b : BL.val_a)), igrad,
+                          (const uint32_t*)(geom + GL.meta) + 2, (uint32_t)R, st);
     if ((rc = debug_sync(s, st, "render backward"))) return rc;
   }
   GsrAdamArgs A;
@@ -598,8 +684,9 @@ int gsr_backward_adam(const gsr_settings* s, const gsr_gaussians* g, const int32
                        scratch, scratch_bytes, grads, opt, stream);
 }
 
-int gsr_adam_step_culled_rows(const gsr_gaussians* g, const void* geometry_state, const gsr_fused_adam* opt, void* stream) {
-  if (!g || !geometry_state || !opt || opt->sparse == 1) {
+int gsr_adam_step_culled_rows(const gsr_gaussians* g, const void* geometry_state, int64_t num_rendered,
+                              const gsr_fused_adam* opt, void* stream) {
+  if (!g || !geometry_state || !opt || opt->sparse == 1 || num_rendered < 0 || num_rendered > 0x3FFFFFFFll) {
     gsr_set_error("adam_step_culled_rows: bad arguments (dense Adam only)");
     return GSR_ERR_INVALID_ARGUMENT;
   }
@@ -613,7 +700,7 @@ int gsr_adam_step_culled_rows(const gsr_gaussians* g, const void* geometry_state
   int rc = adam_args(g, opt, A);
   if (rc) return rc;
   gsr_launch_adam_culled_rows(g->P, g->shs ? g->sh_coeffs : 0, (const char*)geometry_state, gsr_geom_layout(g->P), A,
-                              (hipStream_t)stream);
+                              (uint32_t)num_rendered, (hipStream_t)stream);
   return gsr_launch_status("adam culled rows");
 }
 
@@ -629,7 +716,7 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, u
 
 int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float** rec48,
                              const uint32_t** depth_keys_sorted, const uint32_t** order, const uint32_t** tiles_touched,
-                             const uint16_t** rect, const uint32_t** offsets) {
+                             const uint16_t** rect, const uint32_t** offsets, const uint8_t** clamped) {
   const GsrGeomLayout L = gsr_geom_layout((size_t)(P < 0 ? 0 : P));
   const char* geom = (const char*)geometry_state;
   if (rec48) *rec48 = (const float*)(geom + L.rec);
@@ -638,6 +725,7 @@ int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float*
   if (tiles_touched) *tiles_touched = (const uint32_t*)(geom + L.tiles_touched);
   if (rect) *rect = (const uint16_t*)(geom + L.rect);
   if (offsets) *offsets = (const uint32_t*)(geom + L.offsets);
+  if (clamped) *clamped = (const uint8_t*)(geom + L.clamped);
   return 0;
 }
 

@@ -222,6 +222,13 @@ __device__ __forceinline__ uint32_t gsr_eff_n(const uint32_t* __restrict__ n_dev
   return (hi != 0u || lo > cap) ? cap : lo;
 }
 
+// A frame of the non-blocking forward that had MORE instances than its binning state could hold was composited from a truncated
+// list: its image is not the frame's image, so nothing may be learnt from it.  Every backward kernel tests this (one scalar
+// load) and turns the whole step into a no-op: no gradient records, zero gradients, no optimizer update, no statistics.
+__device__ __forceinline__ bool gsr_overflowed(const uint32_t* __restrict__ n_dev, uint32_t cap) {
+  return n_dev != nullptr && (n_dev[1] != 0u || n_dev[0] > cap);
+}
+
 // One Adam update, shared by k_adam (adam.hip) and the step folded into k_preprocess_bwd (preprocess.hip): every rounding is
 // spelled out (explicit fma / separate operations) so that both kernels produce the same bits whatever the compiler would
 // contract in their different surroundings.  ADAM = 1: torch.optim.Adam (exp_avg.lerp_, bias-corrected step, eps after the

@@ -447,9 +447,14 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
 
 // Start slot of every projection workgroup's instances (exclusive prefix sum of block_sums) and num_rendered (64-bit, into
 // meta[2..3]) - ONE workgroup; 3907 sums at 1 M Gaussians.
+// `early` (optional): the device-side alias of a pinned host word; the count goes there as ONE 8-byte store, tagged valid and
+// carrying the "prefiltered point culled" flag of meta[1] (final since the projection kernel), for a host that waits for the
+// count while the rest of the frame is still queued (api.hip, wait_for_count).
 __global__ __launch_bounds__(1024) void k_scan_block_sums(int nb, const uint32_t* __restrict__ block_sums,
                                                          uint32_t* __restrict__ block_offs,
-                                                         unsigned long long* __restrict__ total) {
+                                                         unsigned long long* __restrict__ total,
+                                                         const uint32_t* __restrict__ flags,
+                                                         unsigned long long* __restrict__ early) {
   __shared__ unsigned long long wsum[16];
   __shared__ unsigned long long carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -472,13 +477,20 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(int nb, const uint32_t
     __syncthreads();
     carry = carry_s;
   }
-  if (tid == 0) *total = carry;
+  if (tid == 0) {
+    *total = carry;
+    if (early)
+      __hip_atomic_store(early, (1ull << 63) | ((unsigned long long)(flags[0] & 1u) << 62) | (carry & ((1ull << 62) - 1ull)),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
-void gsr_launch_scan_block_sums(int P, char* geom, const GsrGeomLayout& L, uint32_t* meta, hipStream_t st) {
+void gsr_launch_scan_block_sums(int P, char* geom, const GsrGeomLayout& L, uint32_t* meta, unsigned long long* early,
+                                hipStream_t st) {
   const int nb = (P + 255) / 256;
   GSR_LAUNCH("scan_block_sums", k_scan_block_sums, dim3(1), dim3(1024), 0, st, nb, (const uint32_t*)(geom + L.offsets),
-             (uint32_t*)(geom + L.offsets) + nb, reinterpret_cast<unsigned long long*>(meta + 2));
+             (uint32_t*)(geom + L.offsets) + nb, reinterpret_cast<unsigned long long*>(meta + 2),
+             (const uint32_t*)(meta + 1), early);
 }
 
 // num_rendered = sum of tiles_touched does not depend on the depth order: summed right after the projection (integer
@@ -644,7 +656,10 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
   const int K = (deg + 1) * (deg + 1);
   // A Gaussian that reached no tile (culled, or its alpha >= 1/255 ellipse misses every tile centre row) has no gradient
   // records: all its gradients are exact zeros, written below without touching its inputs.
-  const bool visible = tiles_touched[idx] > 0;
+  // A frame whose instance list was truncated (non-blocking forward beyond its capacity) is treated as if NO Gaussian had been
+  // visible: zero gradients everywhere, and neither the folded optimizer step nor the folded statistics happen (gsr_overflowed).
+  const bool overflow = gsr_overflowed(n_dev, cap);       // grid-uniform
+  const bool visible = !overflow && tiles_touched[idx] > 0;
 
   float g_mean[3] = {0.f, 0.f, 0.f};
   float g_m2d[2] = {0.f, 0.f};
@@ -894,12 +909,13 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
     dL_dmeans2D[3 * (size_t)idx + 0] = g_m2d[0];
     dL_dmeans2D[3 * (size_t)idx + 1] = g_m2d[1];
     dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
-    if (st_accum) {     // this view's densification statistics, folded in (gsr_grads.xyz_gradient_accum / denom / max_radii2D)
+    if (st_accum && !overflow) {     // this view's densification statistics, folded in (gsr_grads.xyz_gradient_accum / denom / max_radii2D)
       const int rad = radii[idx];
       if (rad > 0) gsr_densify_stats_update(g_m2d[0], g_m2d[1], rad, st_accum + idx, st_denom + idx, st_max_radii + idx);
     }
   }
   if (ADAM) {
+    if (overflow) return;      // the step is a no-op: parameters and both moments keep their bits
     // ---- optimizer step instead of gradient stores (raw-parameter call form: the gradients above ARE the leaves') ----
     const bool upd = active && (ADAM == 1 || (ADAM == 2 ? radii[idx] > 0 : visible));
     if (upd) {
@@ -1104,8 +1120,10 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
 // another stream WHILE the compositing kernels (VALU-bound, little HBM traffic) run; k_preprocess_bwd<., 3> then updates the
 // rows with instances.  Same adam_elem as everywhere: the two kernels together equal k_preprocess_bwd<., 1> bit for bit.
 __global__ __launch_bounds__(256) void k_adam_culled_rows(int P, int sh_stride, const uint32_t* __restrict__ tiles_touched,
-                                                          const GsrAdamArgs A) {
+                                                          const GsrAdamArgs A, const uint32_t* __restrict__ n_dev,
+                                                          uint32_t cap) {
   __shared__ int32_t culled[256];
+  if (gsr_overflowed(n_dev, cap)) return;   // the other half of the update (k_preprocess_bwd<., 3>) skips the frame too
   const size_t row0 = (size_t)blockIdx.x * 256;
   const int rows = (int)min((size_t)256, (size_t)P - row0);
   const bool mine = (int)threadIdx.x < rows && tiles_touched[row0 + threadIdx.x] == 0;
@@ -1156,9 +1174,9 @@ __global__ __launch_bounds__(256) void k_adam_culled_rows(int P, int sh_stride, 
 }
 
 void gsr_launch_adam_culled_rows(int P, int sh_stride, const char* geom, const GsrGeomLayout& L, const GsrAdamArgs& A,
-                                 hipStream_t st) {
+                                 uint32_t cap, hipStream_t st) {
   GSR_LAUNCH("adam_culled_rows", k_adam_culled_rows, dim3((P + 255) / 256), dim3(256), 0, st, P, sh_stride,
-             (const uint32_t*)(geom + L.tiles_touched), A);
+             (const uint32_t*)(geom + L.tiles_touched), A, (const uint32_t*)(geom + L.meta) + 2, cap);
 }
 
 __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,

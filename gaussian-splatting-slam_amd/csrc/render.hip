@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   float pxe = inside ? pxf : 1.0e15f;
   uint64_t live = BALLOT(inside);
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
-  uint32_t last = 0, visited = 0;
+  uint32_t last = 0, visited = 0, blended = 0;
   int vzero;   // keeps the LDS base in a VGPR (see k_render_bwd)
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   const float4 *s0v = s0 + vzero, *s1v = s1 + vzero, *s2v = s2 + vzero;
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
         const bool stop = ok && test_T < 0.0001f;    // the stopping Gaussian is NOT blended (A.5)
         const bool blend = ok && !stop;
         const float wgt = blend ? alpha * T : 0.f;
+        if (COUNT) blended += blend ? 1u : 0u;
         C0 += b.w * wgt;
         C1 += c.x * wgt;
         C2 += c.y * wgt;
@@ -228,8 +229,11 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
       if (j + 3 < n && live != 0ull) step(a3, b3, j + 3);
     }
   }
-  if (COUNT) {
-    if (inside) pairs[(size_t)py * W + px] = visited;
+  if (COUNT) {   // pairs[0 .. N) = entries evaluated per pixel, pairs[N .. 2N) = entries blended per pixel
+    if (inside) {
+      pairs[(size_t)py * W + px] = visited;
+      pairs[(size_t)W * H + (size_t)py * W + px] = blended;
+    }
     return;
   }
   if (inside) {
@@ -259,8 +263,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
                                                     const float* __restrict__ dL_dpix,
                                                     const float* __restrict__ dL_dinvdepth,
                                                     const uint32_t* __restrict__ slot_of_pos,
-                                                    float4* __restrict__ igrad) {
+                                                    float4* __restrict__ igrad, const uint32_t* __restrict__ n_dev,
+                                                    uint32_t cap) {
   __shared__ float4 s0[BWD_BATCH + 6], s1[BWD_BATCH + 6], s2[BWD_BATCH];  // +6: the prefetch may touch [n+5]
+  if (gsr_overflowed(n_dev, cap)) return;   // grid-uniform: a truncated frame teaches nothing (gsr_common.h)
   // one private slab per wave: no LDS atomics, and the 4 partial sums are added in a FIXED order at flush time,
   // so gradients are bitwise reproducible
   __shared__ float4 slab[4][BWD_BATCH * GSR_IGRAD_F4];
@@ -445,8 +451,10 @@ __global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x
                                                         const float* __restrict__ dL_dpix,
                                                         const float* __restrict__ dL_dinvdepth,
                                                         const uint32_t* __restrict__ slot_of_pos,
-                                                        float4* __restrict__ igrad) {
+                                                        float4* __restrict__ igrad, const uint32_t* __restrict__ n_dev,
+                                                        uint32_t cap) {
   __shared__ float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH];   // +2: the prefetch may touch [n+1]
+  if (gsr_overflowed(n_dev, cap)) return;   // grid-uniform: a truncated frame teaches nothing (gsr_common.h)
   __shared__ float4 outb[BWD1_BATCH * GSR_IGRAD_F4];                          // the batch's gradient records
   const int tile = blockIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -606,7 +614,7 @@ void gsr_launch_count_pairs(const gsr_settings* s, int tiles, int grid_x, const 
 void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,
                            const uint32_t* point_list, const float4* rec, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dinvdepth,
-                           const uint32_t* slot_of_pos, float4* igrad, hipStream_t st) {
+                           const uint32_t* slot_of_pos, float4* igrad, const uint32_t* n_dev, uint32_t cap, hipStream_t st) {
   // One wave per tile needs enough tiles to keep 1024 SIMDs busy: below ~6 tiles per SIMD (720p: 3600 tiles) the four-waves-per-tile form
   // (same results up to summation order inside a tile) has the shorter critical path.  GSR_BWD_FORM=quad|tile forces one.
   static const char* form = getenv("GSR_BWD_FORM");
@@ -614,16 +622,16 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
   if (!quad || (form && !strcmp(form, "tile"))) {
     if (dL_dinvdepth)
       GSR_LAUNCH("render_bwd", k_render_bwd_tile<true>, dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height,
-                 grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
+                 grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap);
     else
       GSR_LAUNCH("render_bwd", k_render_bwd_tile<false>, dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height,
-                 grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
+                 grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap);
     return;
   }
   if (dL_dinvdepth)
     GSR_LAUNCH("render_bwd", k_render_bwd<true>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height,
-               grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
+               grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap);
   else
     GSR_LAUNCH("render_bwd", k_render_bwd<false>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height,
-               grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad);
+               grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap);
 }

@@ -74,16 +74,21 @@ EXPORTS = {
                                            C.c_int32, C.c_void_p, C.c_void_p]),
     "gsr_forward_async": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                    C.POINTER(C.c_int64)]),
+    "gsr_forward_rerender": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.POINTER(gsr_grads), C.c_void_p]),
     "gsr_backward_adam": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.POINTER(gsr_grads), C.POINTER(gsr_fused_adam), C.c_void_p]),
-    "gsr_adam_step_culled_rows": (C.c_int, [C.POINTER(gsr_gaussians), C.c_void_p, C.POINTER(gsr_fused_adam), C.c_void_p]),
+    "gsr_adam_step_culled_rows": (C.c_int, [C.POINTER(gsr_gaussians), C.c_void_p, C.c_int64, C.POINTER(gsr_fused_adam),
+                                            C.c_void_p]),
     "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gsr_debug_geometry_views": (C.c_int, [C.c_void_p, C.c_int32] + [C.POINTER(C.c_void_p)] * 6),
+    "gsr_debug_geometry_views": (C.c_int, [C.c_void_p, C.c_int32] + [C.POINTER(C.c_void_p)] * 7),
     "gsr_debug_wave_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_binning_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p)]),
@@ -118,7 +123,7 @@ EXPORTS = {
     "gsr_profile_read": (C.c_int32, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }
 
-ABI_VERSION = 3      # GSR_ABI_VERSION of include/gsr.h
+ABI_VERSION = 4      # GSR_ABI_VERSION of include/gsr.h
 _lib = None
 
 

@@ -133,9 +133,26 @@ def _fused_adam_struct(opt, tensors, advance=True, rows=None):
     return fa, keep
 
 
+def last_ticket(device=None):
+    """Ticket of the most recent speculative forward on this device (1, 2, ...): what `take_overflowed` reports."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return _ws.pool(dev).ticket
+
+
+def take_overflowed(device=None, wait=False):
+    """"async" mode: tickets of the frames found truncated (binning capacity exceeded; their backward was a no-op) among the
+    statuses that have arrived since the last call.  The caller runs those views again."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    p = _ws.pool(dev)
+    p.poll(wait=wait)
+    return p.take_overflowed()
+
+
 def call_stats(device=None, wait=True):
-    """Statistics of this device's rasterizer calls: `num_rendered` of the most recent frame whose count has arrived,
-    `overflow_frames`, `async_frames`, `sync_frames`.  wait=True first waits for the counts still in flight."""
+    """Statistics of this device's rasterizer calls: `num_rendered` of the most recent frame whose count has arrived;
+    frames by mode (`exact_frames`, `async_frames`, `sync_frames`); `rerendered_frames` ("exact": frames whose capacity did
+    not hold and whose phase 2 was repeated), `overflow_frames` ("async": frames composited from a truncated list).
+    wait=True first waits for the counts still in flight."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     p = _ws.pool(dev)
     p.poll(wait=wait)
@@ -230,28 +247,48 @@ class _RasterizeGaussians(torch.autograd.Function):
             key = (P, W, H)
             stream = _stream()
             try:
-                if _ws.forward_mode() == "async" and not rs.debug and not rs.prefiltered and P > 0 and \
-                        key in pool.capacity:
-                    # non-blocking: the binning state is sized from the instance counts this shape has shown so far; the
-                    # count of THIS frame arrives in pinned memory and is looked at by a later call (pool.poll)
-                    R = pool.capacity[key]
+                mode = _ws.forward_mode()
+                if mode != "sync" and not rs.debug and not rs.prefiltered and P > 0:
+                    # speculative: the whole frame is enqueued for the capacity this shape has shown so far.  "exact" then
+                    # waits for THIS frame's count (it reaches pinned memory while the binning / compositing stages are still
+                    # queued, so the device keeps working) and repeats phase 2 if the capacity did not hold; "async" does not
+                    # wait: the count arrives in the pinned status slot and is looked at by a later call (pool.poll)
+                    R = pool.capacity_for_frame(key)
                     binning = ws.ensure_binning(lib, P, W, H, R)
                     status = pool.status_slot()
                     status[2] = 0
                     tlo = 1 if _ws.tile_local_binning(pool, key) else 0
+                    count = C.c_int64(-1)
+                    verify = mode == "exact"
                     _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
                                                    _C.ptr(binning), binning.numel(), R, _C.ptr(img), img.numel(),
                                                    _C.ptr(color), _C.ptr(invdepth), 1 if needs_grad else 0,
-                                                   1 if split else 0, evh, C.c_void_p(status.data_ptr()), tlo, stream))
+                                                   1 if split else 0, evh, C.c_void_p(status.data_ptr()), tlo, stream,
+                                                   C.byref(count) if verify else None))
+                    pool.ticket += 1
                     pool.stats["tile_local_frames"] = pool.stats.get("tile_local_frames", 0) + tlo
+                    if verify:
+                        n = int(count.value)
+                        if n > R:
+                            # the frame just enqueued was composited from a truncated list: same frame again, phase 2 only, on a
+                            # binning state that holds it (stream-ordered behind the first attempt, which stays inside its buffers)
+                            pool.stats["rerendered_frames"] += 1
+                            R = _ws._capacity_for(n)
+                            binning = ws.ensure_binning(lib, P, W, H, R)
+                            _C.check(lib.gsr_forward_rerender(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning),
+                                                              binning.numel(), R, _C.ptr(img), img.numel(), _C.ptr(color),
+                                                              _C.ptr(invdepth), 1 if needs_grad else 0, tlo,
+                                                              C.c_void_p(status.data_ptr()), stream))
+                        pool.note(key, n)
+                        pool.stats["exact_frames"] += 1
+                    else:
+                        pool.stats["async_frames"] += 1
                     done = torch.cuda.Event()
                     done.record()
-                    pool.pending.append((done, status, R, key))
-                    pool.stats["async_frames"] += 1
+                    pool.pending.append((done, status, R, key, pool.ticket, verify))
                 else:
-                    # blocking read-back of num_rendered (the published rasterizer's one host synchronisation): the first
-                    # frame of a shape, debug mode, prefiltered=True (its "culled point" error is raised by this very call), or
-                    # GSR_FORWARD_MODE=sync
+                    # blocking read-back of num_rendered (the published rasterizer's one host synchronisation): debug mode,
+                    # prefiltered=True (its "culled point" error is raised by this very call), or GSR_FORWARD_MODE=sync
                     prepare = lib.gsr_forward_prepare_geometry if split else lib.gsr_forward_prepare
                     R = _C.check(prepare(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii), stream))
                     pool.note(key, R)
@@ -351,7 +388,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                 side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
                             side.wait_stream(torch.cuda.current_stream())
                             with torch.cuda.stream(side):
-                                _C.check(lib.gsr_adam_step_culled_rows(C.byref(g), _C.ptr(geom), C.byref(fused[0]),
+                                _C.check(lib.gsr_adam_step_culled_rows(C.byref(g), _C.ptr(geom), R, C.byref(fused[0]),
                                                                        _stream()))
                         _C.check(lib.gsr_backward_adam(C.byref(s), C.byref(g), _C.ptr(radii), _C.ptr(geom),
                                                        _C.ptr(binning), _C.ptr(img), R, _C.ptr(grad_color),
@@ -386,7 +423,8 @@ def pair_evaluations(raster_settings, means3D, opacities, shs=None, colors_preco
                      cov3D_precomp=None, dc=None, raw_activations=False):
     """Pixel-Gaussian pair evaluations of one view (SURVEY.md 8(d) "FLOP model"), for the bench's pairs/s figures:
     {"num_rendered", "fwd_pairs": list entries evaluated by the compositing forward summed over pixels (instrumented build of
-    the forward kernel), "bwd_pairs": sum of n_contrib (the backward replays entries 1..n_contrib of every pixel)}."""
+    the forward kernel), "fwd_blended": those of them that were blended, "bwd_pairs": sum of n_contrib (the backward replays
+    entries 1..n_contrib of every pixel)}."""
     lib = _C.lib()
     rs = raster_settings
     dev = means3D.device
@@ -405,13 +443,14 @@ def pair_evaluations(raster_settings, means3D, opacities, shs=None, colors_preco
         binning = torch.empty(lib.gsr_binning_state_bytes(P, W, H, R), dtype=torch.uint8, device=dev)
         _C.check(lib.gsr_forward_render(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning), binning.numel(), R,
                                         _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invd), 1, _stream()))
-        pairs = torch.zeros(H * W, dtype=torch.int32, device=dev)
+        pairs = torch.zeros(2 * H * W, dtype=torch.int32, device=dev)
         _C.check(lib.gsr_debug_count_pairs(C.byref(s), P, _C.ptr(geom), _C.ptr(binning), R, _C.ptr(pairs), _stream()))
         pT, pN = C.c_void_p(), C.c_void_p()
         lib.gsr_debug_image_views(_C.ptr(img), W, H, C.byref(pT), C.byref(pN))
         off = pN.value - img.data_ptr()
         n_contrib = img[off:off + 4 * H * W].view(torch.int32)
-        out = {"num_rendered": int(R), "fwd_pairs": int(pairs.sum(dtype=torch.int64).item()),
+        out = {"num_rendered": int(R), "fwd_pairs": int(pairs[:H * W].sum(dtype=torch.int64).item()),
+               "fwd_blended": int(pairs[H * W:].sum(dtype=torch.int64).item()),
                "bwd_pairs": int(n_contrib.sum(dtype=torch.int64).item())}
     return out
 

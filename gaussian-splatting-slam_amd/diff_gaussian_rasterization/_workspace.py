@@ -1,15 +1,20 @@
-"""Grow-only state buffers for the rasterizer and the bookkeeping of the non-blocking forward.
+"""Grow-only state buffers for the rasterizer and the bookkeeping of the speculative forward.
 
-The published rasterizer (and `gsr_forward_prepare`) reads `num_rendered` back to the host in every forward to size its
-binning buffer: one blocking wait per frame, and a differently sized `torch.empty` per view, which keeps the caching
-allocator growing for a whole pass over the views.  Here every in-flight forward -> backward pair leases one `Workspace`
-(geometry / binning / image state + the backward's gradient records) from a per-device pool; buffers only ever grow
-(geometrically), and once the instance count of a shape (P, W, H) is known the forward goes through `gsr_forward_async`:
-no wait, `num_rendered` arrives in pinned memory and is looked at by a LATER call (`Pool.poll`), where it raises the capacity
-estimate for the next frames.  A frame whose count exceeds the estimate loses instances (the farthest ones in the global binning
-form, arbitrary ones in the tile-local form, which is why that form waits for a settled capacity; include/gsr.h,
-gsr_forward_async) and is counted in `stats["overflow_frames"]`; `set_forward_mode("sync")` / GSR_FORWARD_MODE=sync keeps the
-blocking read-back for callers that cannot accept that.
+The published rasterizer (and `gsr_forward_prepare`) reads `num_rendered` back to the host in the MIDDLE of every forward to
+size its binning buffer: the device idles while the host wakes up, allocates and enqueues the rest, and every view gets a
+differently sized `torch.empty`.  Here every in-flight forward -> backward pair leases one `Workspace` (geometry / binning /
+image state + the backward's gradient records) from a per-device pool; buffers only ever grow, and the forward is enqueued
+WHOLE through `gsr_forward_async`, sized by a capacity estimate for its shape (P, W, H).  Three modes:
+
+  "exact" (default)  verified speculation: once the frame is enqueued the call waits for the frame's count, which the device
+                     delivers to pinned memory as soon as it is known (the binning and compositing stages are still queued
+                     behind it, so the device never idles), and if the count exceeds the capacity the binning state grows and
+                     `gsr_forward_rerender` repeats phase 2.  EVERY frame is the blocking path's frame, bit for bit.
+  "async"            no wait at all (a host-bound loop).  A frame beyond the capacity is composited from a truncated list; the
+                     device-side guard (gsr_common.h, gsr_overflowed) makes its backward a no-op - zero gradients, no folded
+                     optimizer step, no folded statistics - and the frame's ticket is reported by `take_overflowed()` as soon
+                     as its status has arrived, so the caller can run that view again (scene_utils/trainer.py does).
+  "sync"             the published blocking read-back (`gsr_forward_prepare` + `gsr_forward_render`).
 """
 from __future__ import annotations
 
@@ -22,24 +27,25 @@ import torch
 
 from . import _C
 
-_MODE = os.environ.get("GSR_FORWARD_MODE", "async").lower()
-# binning form of the non-blocking forward: "tile" (tile-local depth ordering, include/gsr.h gsr_forward_async) unless a
+_MODES = ("exact", "async", "sync")
+_MODE = os.environ.get("GSR_FORWARD_MODE", "exact").lower()
+if _MODE not in _MODES:
+    raise ValueError(f"GSR_FORWARD_MODE={_MODE!r}: expected one of {_MODES}")
+# binning form of the speculative forward: "tile" (tile-local depth ordering, include/gsr.h gsr_forward_async) unless a
 # shape's lists get too long for it, or "global" (GSR_BINNING=global: always the global depth sort of the blocking path)
 _BINNING = os.environ.get("GSR_BINNING", "tile").lower()
 TLO_MAX_LIST = 3072      # 75 % of the kernel's LDS capacity (4096 entries): beyond that a shape goes back to the global form
-# The tile-local form emits in index order, so a frame beyond the capacity loses ARBITRARY instances where the global form
-# loses the farthest ones (usually invisible).  It is therefore used only once a shape's capacity has held for this many
-# consecutive frames (GSR_TLO_SETTLE); any raise of the capacity starts the count again.
-TLO_SETTLE_FRAMES = int(os.environ.get("GSR_TLO_SETTLE", "3"))
 HEADROOM = float(os.environ.get("GSR_HEADROOM", "1.5"))    # capacity = max(num_rendered seen for this shape) * HEADROOM (1.25 -> 1.5 costs ~1 us per frame at C3)
 MIN_CAPACITY = 1 << 14
+FIRST_GUESS_PER_GAUSSIAN = 6      # capacity of a shape's first frame: 6 tile instances per Gaussian (C1-C5: 1.3 - 13; a low guess costs one re-render)
 
 
 def set_forward_mode(mode: str):
-    """"async" (default): non-blocking forward once a shape's instance count is known.  "sync": always the blocking
-    read-back of the published rasterizer (exact for every frame, the host stays at most one frame ahead)."""
+    """"exact" (default): speculative forward, count verified before the call returns - every frame exact.  "async": no wait;
+    an overflowed frame's backward is a no-op and its ticket is reported (take_overflowed).  "sync": always the blocking
+    read-back of the published rasterizer."""
     global _MODE
-    if mode not in ("async", "sync"):
+    if mode not in _MODES:
         raise ValueError(mode)
     _MODE = mode
 
@@ -49,8 +55,7 @@ def forward_mode() -> str:
 
 
 def tile_local_binning(pool, key) -> bool:
-    return (_BINNING == "tile" and pool.longest_list.get(key, 0) <= TLO_MAX_LIST
-            and pool.settled.get(key, 0) >= TLO_SETTLE_FRAMES)
+    return _BINNING == "tile" and pool.longest_list.get(key, 0) <= TLO_MAX_LIST
 
 
 def _capacity_for(R: int) -> int:
@@ -111,11 +116,12 @@ class Pool:
         self.free = []
         self.capacity = {}                       # (P, W, H) -> instances the binning state is sized for
         self.longest_list = {}                   # (P, W, H) -> longest tile list seen (tile-local binning form)
-        self.settled = {}                        # (P, W, H) -> frames noted since the capacity last changed
-        self.pending = collections.deque()       # (event, pinned status, capacity used, key)
+        self.pending = collections.deque()       # (event, pinned status, capacity used, key, ticket, count already verified)
         self.status_free = []
-        self.stats = {"num_rendered": 0, "overflow_frames": 0, "async_frames": 0, "sync_frames": 0}
-        self._warned = False
+        self.ticket = 0                          # frames handed to gsr_forward_async so far
+        self.overflowed = []                     # tickets of unverified frames that turned out to be truncated
+        self.stats = {"num_rendered": 0, "overflow_frames": 0, "async_frames": 0, "sync_frames": 0, "exact_frames": 0,
+                      "rerendered_frames": 0}
 
     # ---- workspaces ----
     def acquire(self) -> Workspace:
@@ -146,24 +152,28 @@ class Pool:
             return self.status_free.pop()
         return torch.zeros(4, dtype=torch.int64).pin_memory()    # [flags word 0|1, num_rendered, longest list|-, -]
 
+    def capacity_for_frame(self, key):
+        """Capacity the next frame of this shape is enqueued with: what the shape has shown so far (plus headroom), or a guess
+        for its first frame."""
+        cap = self.capacity.get(key)
+        return cap if cap is not None else max(MIN_CAPACITY, (FIRST_GUESS_PER_GAUSSIAN * key[0] + 4095) & ~4095)
+
     def note(self, key, R):
         self.stats["num_rendered"] = int(R)
         cap = self.capacity.get(key)
         if cap is None or R * 1.1 > cap:
             self.capacity[key] = _capacity_for(R)
-            self.settled[key] = 0
-        else:
-            self.settled[key] = self.settled.get(key, 0) + 1
 
     def forget_estimates(self):
-        """Drops what was learnt per shape (capacities, list lengths): the next frame of every shape blocks once again."""
+        """Drops what was learnt per shape (capacities, list lengths)."""
         self.poll(wait=True)
-        self.capacity.clear(); self.longest_list.clear(); self.settled.clear()
+        self.capacity.clear(); self.longest_list.clear()
+        self.overflowed.clear()
 
     def poll(self, wait=False):
-        """Looks at the statuses of earlier non-blocking forwards that have completed (all of them with wait=True)."""
+        """Looks at the statuses of earlier speculative forwards that have completed (all of them with wait=True)."""
         while self.pending:
-            ev, status, cap, key = self.pending[0]
+            ev, status, cap, key, ticket, verified = self.pending[0]
             if wait:
                 ev.synchronize()
             elif not ev.query():
@@ -173,16 +183,22 @@ class Pool:
             longest = int(status[2]) & 0xFFFFFFFF
             self.longest_list[key] = max(self.longest_list.get(key, 0), longest)
             self.status_free.append(status)
+            if verified:        # "exact" mode: the count was looked at (and acted upon) before the forward returned
+                continue
             if (flags >> 32) & 1:
                 raise _C.GsrError("Point is filtered although prefiltered is set. This shouldn't happen!")
             if R > cap or R < 0:
                 self.stats["overflow_frames"] += 1
-                if not self._warned:
-                    self._warned = True
-                    warnings.warn(f"gsr: a frame had {R} tile instances, capacity was {cap}: the instances beyond it "
-                                  "(the farthest ones, or arbitrary ones in the tile-local binning form) were dropped "
-                                  "for that frame; the capacity has been raised (GSR_FORWARD_MODE=sync avoids this)")
+                self.overflowed.append(ticket)
+                warnings.warn(f"gsr: frame {ticket} (P, W, H = {key}) had {R} tile instances, the binning state held {cap}: it was "
+                              "composited from a truncated list and its backward was a no-op; the capacity has been raised "
+                              "(forward mode 'exact', the default, re-renders such a frame instead)", RuntimeWarning)
             self.note(key, R if R >= 0 else 0x7FFFFFFF // 2)
+
+    def take_overflowed(self):
+        """Tickets (see `last_ticket`) of unverified frames found truncated since the last call."""
+        out, self.overflowed = self.overflowed, []
+        return out
 
 
 _pools = {}

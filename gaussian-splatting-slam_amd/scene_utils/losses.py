@@ -1,10 +1,8 @@
-"""Loss / metric definitions used around the rasterizer path (callers of the hot path; plain PyTorch).
-Restates reference utils/loss_utils.py:40-52 (l1_loss), :100-159 (ssim: 11x11 Gaussian window, sigma 1.5,
-zero padding, C1=0.01^2, C2=0.03^2) and utils/image_utils.py:17-19 (psnr); pinned by tests/golden/reference_helpers.npz."""
-import math
-
+"""Loss / metric entry points used around the rasterizer path (callers of the hot path).
+`l1_loss` / `psnr`: reference utils/loss_utils.py:40-52, utils/image_utils.py:17-19 (pinned by tests/golden/reference_helpers.npz).
+The training loss of reference train.py:114-121 is computed by the fused HIP kernels (csrc/ssim.hip); its pure-PyTorch
+restatement, the checker of those kernels, lives in oracle/loss_oracle.py and is not part of the product."""
 import torch
-import torch.nn.functional as F
 
 
 def l1_loss(network_output, gt):
@@ -14,44 +12,6 @@ def l1_loss(network_output, gt):
 def psnr(img1, img2):
     mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
     return 20 * torch.log10(1.0 / torch.sqrt(mse))
-
-
-_window_cache = {}
-
-
-def _window(window_size, channel, like):
-    key = (window_size, channel, like.device, like.dtype)
-    w = _window_cache.get(key)
-    if w is None:
-        g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
-        g = (g / g.sum()).unsqueeze(1)
-        w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
-        w = w2.expand(channel, 1, window_size, window_size).contiguous().to(device=like.device, dtype=like.dtype)
-        _window_cache[key] = w
-    return w
-
-
-def ssim(img1, img2, window_size=11, size_average=True):
-    channel = img1.size(-3)
-    window = _window(window_size, channel, img1)
-    pad = window_size // 2
-    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
-    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
-    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
-    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
-    if size_average:
-        return ssim_map.mean()
-    return ssim_map.mean(1).mean(1).mean(1)
-
-
-def training_loss(image, gt_image, lambda_dssim=0.2):
-    """reference train.py:114-121 with the pure-PyTorch ssim() (the FUSED_SSIM_AVAILABLE == False branch)."""
-    Ll1 = l1_loss(image, gt_image)
-    return (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt_image))
 
 
 def training_loss_fused(image, gt_image, lambda_dssim=0.2):

@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import torch
 
-from .losses import training_loss, training_loss_fused
+from .losses import training_loss_fused
 from .parallel import GradBucket, reduce_densification_stats
 
 
@@ -26,8 +26,8 @@ class Trainer:
                  optimizer="hip", loss="hip", depth_targets=None, depth_weight=0.0, separate_sh=False, overlap_comm=None,
                  exchange="allreduce"):
         """optimizer: "hip" (one-launch HIP Adam, default-optimizer semantics), "hip_sparse" (SparseGaussianAdam, the
-        reference's accelerated choice) or "torch" (torch.optim.Adam; CPU tests).  loss: "hip" (fused SSIM kernels) or
-        "torch" (pure-PyTorch ssim; CPU tests)."""
+        reference's accelerated choice) or "torch" (torch.optim.Adam; CPU tests).  loss: "hip" (fused SSIM kernels) or a
+        callable (image, gt_image, lambda_dssim) -> scalar (the CPU tests hand in the oracle's pure-PyTorch loss)."""
         self.model, self.cameras, self.gt_images = model, cameras, gt_images
         self.render_fn, self.pipe, self.bg = render_fn, pipe, bg
         self.lambda_dssim = lambda_dssim
@@ -44,7 +44,9 @@ class Trainer:
         self.optimizer_kind = optimizer
         # like the reference, the model owns the optimizer and the densification statistics (gaussian_model.py:155-176)
         self.optimizer = model.training_setup(optimizer=optimizer)
-        self.loss_fn = {"hip": training_loss_fused, "torch": training_loss}[loss]
+        if not callable(loss) and loss != "hip":
+            raise ValueError("loss: 'hip' or a callable (the pure-PyTorch loss is test infrastructure: oracle/loss_oracle.py)")
+        self.loss_fn = loss if callable(loss) else training_loss_fused
         self.bucket = GradBucket(model.parameters()) if world > 1 else None
         # N > 1 gradient exchange: "allreduce" (one all-reduce per leaf, every rank runs the whole update),
         # "visible_rows" (the same, restricted to the rows some rank saw), "sharded" (reduce-scatter -> Adam on a 1/N row shard
@@ -82,6 +84,8 @@ class Trainer:
         self.iteration = 0
         self._one = None                 # cached dL/dloss = 1 for loss.backward()
         self.last = {}
+        self._ticket_view = {}           # forward mode "async": rasterizer ticket -> view of the frames still unverified
+        self.rerun_views = 0             # ... and how many truncated frames were run again
 
     # statistics live in the model (reference: GaussianModel.xyz_gradient_accum / denom / max_radii2D)
     @property
@@ -108,9 +112,15 @@ class Trainer:
         """One optimizer step.  `view_idx`: one view (the reference's batch-1 step) or a list of views whose gradients are
         accumulated locally before the single cross-rank exchange and the single Adam step (gradient accumulation)."""
         views = list(view_idx) if isinstance(view_idx, (list, tuple)) else [view_idx]
+        unverified = self.model.get_xyz.is_cuda and self._unverified_mode()
+        if unverified:
+            self._rerun_truncated_frames()
         for n, v in enumerate(views):
             cam = self.cameras[v]
             pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh)
+            if unverified:
+                import diff_gaussian_rasterization as dgr
+                self._ticket_view[dgr.last_ticket(self.model.get_xyz.device)] = v
             image, vsp, radii = pkg["render"], pkg["viewspace_points"], pkg["radii"]
             vis = _LazyVisibility(pkg)       # `radii > 0`: only materialised by the branches that use it
             loss = self.loss_fn(image, self.gt_images[v], self.lambda_dssim)
@@ -183,6 +193,37 @@ class Trainer:
             self.optimizer.zero_grad(set_to_none=True)
         return self.last
 
+    @staticmethod
+    def _unverified_mode():
+        import diff_gaussian_rasterization as dgr
+        return dgr.forward_mode() == "async"
+
+    def _rerun_truncated_frames(self, wait=False):
+        """Forward mode "async" only.  A frame that had more tile instances than its binning state held was composited from a
+        truncated list; the rasterizer's backward then did nothing (zero gradients; with the optimizer folded in: parameters,
+        moments and statistics bit-unchanged) and reports the frame's ticket once its status has arrived.  Such a view is run
+        again here, verified, as one more iteration - before the next view is touched."""
+        import diff_gaussian_rasterization as dgr
+        dev = self.model.get_xyz.device
+        for t in dgr.take_overflowed(dev, wait=wait):
+            v = self._ticket_view.pop(t, None)
+            if v is None:
+                continue
+            if self.fuse_step and self.world == 1:
+                # the folded step that did not happen was counted on the host: the bias correction must not see it
+                for st in self.optimizer.state.values():
+                    if "step" in st and float(st["step"]) > 0:
+                        st["step"] -= 1
+            self.rerun_views += 1
+            dgr.set_forward_mode("exact")
+            try:
+                self.step(v)
+            finally:
+                dgr.set_forward_mode("async")
+        if len(self._ticket_view) > 256:      # statuses arrive in order: anything older than the newest 64 is long verified
+            for t in sorted(self._ticket_view)[:-64]:
+                del self._ticket_view[t]
+
     def _densify_due(self, it=None):
         d, it = self.densify, (self.iteration if it is None else it)
         if d is None or it >= d["until_iter"]:
@@ -237,6 +278,8 @@ class Trainer:
         ev = getattr(self, "_pending_sh_event", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
+        if self.model.get_xyz.is_cuda and self._unverified_mode():
+            self._rerun_truncated_frames(wait=True)      # nothing truncated is left behind
 
     def _maybe_densify(self, radii):
         d, it = self.densify, self.iteration

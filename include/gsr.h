@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 
 enum {
   GSR_OK = 0,
@@ -146,13 +146,24 @@ int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void
                              size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
                              void* sh_ready_event, void* stream);
 
-/* Non-blocking forward (phase 1 + phase 2 in one call, NO wait for the device): for callers that keep grow-only state
- * buffers and cannot afford the reference rasterizer's one host read-back per frame (a SLAM / training loop enqueues several
- * frames ahead).  The binning state is sized by the caller for `capacity` instances (gsr_binning_state_bytes(.., capacity));
- * num_rendered stays on the device and every later stage reads min(num_rendered, capacity) from there.  If a frame has MORE
- * instances than `capacity`, the surplus - emitted last: its farthest splats with tile_local_sort = 0, the Gaussians with the
- * highest indices with tile_local_sort = 1 - is dropped for that frame (never an out-of-bounds access); the caller learns it
- * from `host_status` and grows its buffers for the next frame.
+/* Speculative forward (phase 1 + phase 2 in ONE call, sized by the caller's estimate): for callers that keep grow-only state
+ * buffers (a SLAM / training loop).  The reference's rasterizer reads num_rendered back in the middle of every forward to size
+ * its binning buffer (SURVEY.md 2.3 "D2H num_rendered"; call site gaussian_renderer/__init__.py:90-109), which leaves the device
+ * idle while the host allocates and enqueues the rest.  Here the binning state is sized by the caller for `capacity` instances
+ * (gsr_binning_state_bytes(.., capacity)), the WHOLE frame is enqueued, num_rendered stays on the device and every later stage
+ * reads min(num_rendered, capacity) from there.  Two ways to use it:
+ *
+ *   verified (num_rendered_out != NULL; what diff_gaussian_rasterization does by default): after everything is enqueued the
+ *     call waits until the count has reached the host - the kernel that knows it stores it straight into pinned memory, with
+ *     the binning and compositing stages still queued behind it, so the device does not idle - and returns it in
+ *     *num_rendered_out.  If it exceeds `capacity` the frame just enqueued was composited from a TRUNCATED instance list: the
+ *     caller grows its binning state and calls gsr_forward_rerender, which repeats phase 2 exactly; outputs and state are then
+ *     those of the blocking pair, bit for bit.  Every frame is exact.
+ *   unverified (num_rendered_out == NULL): no wait at all.  A frame beyond `capacity` loses the surplus - emitted last: its
+ *     farthest splats with tile_local_sort = 0, the Gaussians with the highest indices with tile_local_sort = 1 - never an
+ *     out-of-bounds access; the caller learns it later from `host_status`.  gsr_backward / gsr_backward_adam on such a frame
+ *     are NO-OPS by construction (every backward kernel reads the count): zero gradients, no optimizer update, no statistics.
+ *
  *   host_status: NULL or 8 words of host memory, filled asynchronously on `stream` at the END of the call's work:
  *                [0] reserved, [1] bit 0 = a prefiltered point failed the near-plane test, [2],[3] = num_rendered (lo, hi),
  *                [4] = longest tile list of the frame if it exceeds 2048 entries, else 0 (tile_local_sort only).
@@ -164,8 +175,7 @@ int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void
  *                tile orders ITS list by (depth bits, id) in LDS (binning.hip, k_tile_depth_sort) - identical lists, about
  *                0.07 ms less per frame at 1 M Gaussians / 1080p (the tile counts are then also scanned inside the projection
  *                and emission kernels: four launches fewer); lists longer than 4096 entries take a slow in-memory path, so a
- *                caller should fall back to 0 when host_status[4] approaches that, and should prefer 0 while its capacity
- *                estimate is still moving (diff_gaussian_rasterization/_workspace.py does both).
+ *                caller should fall back to 0 when host_status[4] approaches that (diff_gaussian_rasterization/_workspace.py).
  *   defer_color / sh_ready_event: as gsr_forward_prepare_geometry + gsr_forward_render_shade (0 / NULL: fused colour pass).
  * The matching gsr_backward takes `capacity` as its num_rendered.  Same kernels, same results as the blocking pair whenever
  * num_rendered <= capacity. */
@@ -173,7 +183,15 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
                       int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
                       size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
                       int32_t defer_color, void* sh_ready_event, uint32_t* host_status, int32_t tile_local_sort,
-                      void* stream);
+                      void* stream, int64_t* num_rendered_out /* host, or NULL */);
+
+/* Phase 2 once more on the state a gsr_forward_async call with the same `s`, `g`, geometry / image state and tile_local_sort
+ * left behind, for a (larger) binning state of `capacity` >= the count that call reported: instance emission, tile sort,
+ * ranges, per-tile ordering, compositing.  Stream-ordered behind the first attempt; overwrites its outputs. */
+int gsr_forward_rerender(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,
+                         size_t binning_bytes, int64_t capacity, void* image_state, size_t image_bytes, float* out_color,
+                         float* out_invdepth, int32_t for_backward, int32_t tile_local_sort, uint32_t* host_status,
+                         void* stream);
 
 /* Backward of the calls above.  dL_dinvdepth may be NULL (treated as zero).  `num_rendered`: the value gsr_forward_prepare
  * returned (and gsr_forward_render was given), or the `capacity` given to gsr_forward_async. */
@@ -216,24 +234,29 @@ int gsr_backward_adam(const gsr_settings* s, const gsr_gaussians* g, const int32
 /* Dense Adam update (zero gradient: moments decay, the parameter follows its momentum) of the rows that reached no tile in the
  * forward whose geometry state is given; companion of gsr_backward_adam(opt->sparse = 2).  May be enqueued on any stream once
  * the forward call that filled `geometry_state` has been enqueued and that stream waits for it; the caller orders it before the
- * next forward.  `g` and `opt` as for gsr_backward_adam (same `step` values). */
-int gsr_adam_step_culled_rows(const gsr_gaussians* g, const void* geometry_state, const gsr_fused_adam* opt, void* stream);
+ * next forward.  `g`, `num_rendered` and `opt` as for gsr_backward_adam (same `step` values). */
+int gsr_adam_step_culled_rows(const gsr_gaussians* g, const void* geometry_state, int64_t num_rendered,
+                              const gsr_fused_adam* opt, void* stream);
 
 /* GaussianRasterizer.markVisible (near-plane test).  present[P] uint8. */
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream);
 
 /* Introspection for tests / bench: DEVICE pointers into the opaque state buffers (valid while the buffer lives). */
+/* rec48: the packed 48-B splat records, 12 floats per Gaussian = (mean2D.xy, conic A' B') (conic C', opacity, cut-off, r)
+ * (g, b, 1/depth, depth); clamped: one byte per Gaussian, bit c set = colour channel c was clamped at 0 (any out pointer may
+ * be NULL) */
 int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float** rec48, const uint32_t** depth_keys_sorted,
                              const uint32_t** order, const uint32_t** tiles_touched, const uint16_t** rect,
-                             const uint32_t** offsets);
+                             const uint32_t** offsets, const uint8_t** clamped);
 /* test hook: 64-lane sums through the render backward's cross-lane reductions; in[10][64] -> out[20]:
  * out[0..9] = the ten-value tree, out[10..18] = the nine-value tree on rows 0..8, out[19] unused */
 int gsr_debug_wave_reduce(const float* in640, float* out20, void* stream);
 int gsr_debug_binning_views(const void* binning_state, int32_t image_width, int32_t image_height,
                             int64_t num_rendered, const uint32_t** point_list, const uint32_t** ranges);
-/* Pair evaluations of the compositing forward (SURVEY.md 8(d) "FLOP model"): pairs[H*W] (uint32) = per pixel, the number of
- * list entries evaluated while the pixel was still compositing, counted by an instrumented build of the forward kernel on the
- * state buffers of a finished forward.  (The backward's count is the sum of n_contrib: it replays entries 1..n_contrib.) */
+/* Pair evaluations of the compositing forward (SURVEY.md 8(d) "FLOP model"): pairs[2*H*W] (uint32) = per pixel, the number of
+ * list entries evaluated while the pixel was still compositing [0, H*W) and the number of entries it blended [H*W, 2*H*W),
+ * counted by an instrumented build of the forward kernel on the state buffers of a finished forward.  (The backward's count is
+ * the sum of n_contrib: it replays entries 1..n_contrib.) */
 int gsr_debug_count_pairs(const gsr_settings* s, int32_t P, const void* geometry_state, const void* binning_state,
                           int64_t num_rendered, uint32_t* pairs, void* stream);
 /* test / measurement hook: the library's stable LSD radix sort (sort_scan.hip) on caller-provided ping-pong buffers: keys k0

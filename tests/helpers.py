@@ -137,7 +137,7 @@ def lowlevel_forward(raw, cam, deg, bg, antialiasing=False, device="cuda"):
                                     _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invd), 1, _stream()))
     torch.cuda.synchronize()
     pv = [C.c_void_p() for _ in range(6)]
-    lib.gsr_debug_geometry_views(_C.ptr(geom), P, *[C.byref(p) for p in pv])
+    lib.gsr_debug_geometry_views(_C.ptr(geom), P, *[C.byref(p) for p in pv], None)
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     out = dict(R=R, radii=radii.cpu(), color=color.cpu(), invdepth=invd.cpu())
     out["rec"] = _view(geom, pv[0].value, P * 12, torch.float32).view(P, 12)

@@ -1,7 +1,16 @@
-"""Non-blocking forward (gsr_forward_async: device-side num_rendered, capacity-sized binning state, include/gsr.h) against the
-blocking pair gsr_forward_prepare + gsr_forward_render, which keeps the published rasterizer's one read-back per frame.
-Whenever num_rendered <= capacity the two must agree bit for bit (same kernels, same order); beyond the capacity the frame
-loses its farthest instances, never writes out of bounds, and the next frame is exact again."""
+"""Speculative forward (gsr_forward_async: the whole frame enqueued for a capacity estimate, num_rendered on the device;
+include/gsr.h) against the blocking pair gsr_forward_prepare + gsr_forward_render, which keeps the published rasterizer's
+read-back in the middle of every frame (SURVEY.md 2.3 "D2H num_rendered"; reference call site
+gaussian_renderer/__init__.py:90-109).
+
+  "exact" (the DEFAULT mode): every frame must be the blocking path's frame bit for bit - also a frame with several times the
+      instances its shape (P, W, H) has shown before (the count is verified before the call returns and phase 2 is repeated);
+  "async": bit-identical whenever num_rendered <= capacity; beyond it the frame is composited from a truncated list, never writes
+      out of bounds, its backward is a NO-OP (zero gradients; folded optimizer: parameters, moments, statistics keep their
+      bits), it is reported per frame, and the Trainer runs the view again.
+"""
+import ctypes as C
+
 import pytest
 import torch
 
@@ -11,49 +20,238 @@ from scene_utils import make_gaussians, fibonacci_cameras
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _restore_mode():
+    import diff_gaussian_rasterization as dgr
+    mode = dgr.forward_mode()
+    yield
+    dgr.set_forward_mode(mode)
+
+
 def _views(n=5, P=6000, W=208, H=128):
     raw = make_gaussians(P, 3, seed=301, scale_factor=0.7)
     cams = fibonacci_cameras(n, W, H, seed=302)
     return raw, cams
 
 
-def test_async_forward_and_backward_bit_identical_to_blocking():
+def _thinned(raw, keep_every=5):
+    """The same scene with all but every `keep_every`-th Gaussian made transparent (opacity far below 1/255: no tile
+    instances): a frame of the same (P, W, H) with about 1 / keep_every of the instances."""
+    import copy
+    out = copy.deepcopy(raw)
+    mask = torch.ones(out.opacity.shape[0], dtype=torch.bool)
+    mask[::keep_every] = False
+    out.opacity[mask] = -12.0
+    return out
+
+
+def _same(a, b):
+    assert torch.equal(a["color"], b["color"]) and torch.equal(a["invdepth"], b["invdepth"])
+    assert torch.equal(a["radii"], b["radii"])
+    if a["grads"] is not None:
+        for k in a["grads"]:
+            assert torch.equal(a["grads"][k], b["grads"][k]), k
+
+
+def test_default_mode_is_exact():
+    import os
+    import diff_gaussian_rasterization as dgr
+    if "GSR_FORWARD_MODE" not in os.environ:
+        assert dgr.forward_mode() == "exact"
+
+
+@pytest.mark.parametrize("mode", ["exact", "async"])
+def test_speculative_forward_and_backward_bit_identical_to_blocking(mode):
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _workspace as ws
     raw, cams = _views()
     bg = torch.tensor([0.3, 0.1, 0.2])
     gc, gd = upstream_grads(cams[0].image_height, cams[0].image_width)
     dgr.set_forward_mode("sync")
-    try:
-        ref = [run_hip(raw, c, 3, bg, gc=gc, gd=gd) for c in cams]
-        dgr.set_forward_mode("async")
-        pool = ws.pool(torch.device("cuda", 0))
-        before = dict(pool.stats)
-        outs = [run_hip(raw, c, 3, bg, gc=gc, gd=gd) for c in cams]       # first call of the shape may block, the rest do not
-        stats = dgr.call_stats()
-        assert stats["async_frames"] - before["async_frames"] >= len(cams) - 1
-        assert stats["overflow_frames"] == before["overflow_frames"]
-        for a, b in zip(ref, outs):
-            assert torch.equal(a["color"], b["color"]) and torch.equal(a["invdepth"], b["invdepth"])
-            assert torch.equal(a["radii"], b["radii"])
-            for k in a["grads"]:
-                assert torch.equal(a["grads"][k], b["grads"][k]), k
-        # forward-only (torch.no_grad) takes the same route
-        with torch.no_grad():
-            c = run_hip(raw, cams[1], 3, bg)
-        assert torch.equal(c["color"], ref[1]["color"])
-    finally:
-        dgr.set_forward_mode("async")
+    ref = [run_hip(raw, c, 3, bg, gc=gc, gd=gd) for c in cams]
+    dgr.set_forward_mode(mode)
+    pool = ws.pool(torch.device("cuda", 0))
+    pool.forget_estimates()                    # the first frame of the shape is speculative too (capacity guessed from P)
+    before = dict(pool.stats)
+    outs = [run_hip(raw, c, 3, bg, gc=gc, gd=gd) for c in cams]
+    stats = dgr.call_stats()
+    assert stats[mode + "_frames"] - before[mode + "_frames"] == len(cams)
+    assert stats["sync_frames"] == before["sync_frames"]
+    assert stats["overflow_frames"] == before["overflow_frames"]
+    for a, b in zip(ref, outs):
+        _same(a, b)
+    # forward-only (torch.no_grad, reference render.py:49) takes the same route
+    with torch.no_grad():
+        c = run_hip(raw, cams[1], 3, bg)
+    assert torch.equal(c["color"], ref[1]["color"])
 
 
 @pytest.mark.parametrize("tile_local", [False, True])
-def test_async_capacity_overflow_is_contained_and_heals(tile_local, monkeypatch):
-    """Force a capacity far below the instance count: the frame renders from a truncated list (nearest-first in the global
-    binning form, lowest ids first in the tile-local form) without touching memory outside its buffers, the overflow is
-    counted, the capacity is raised, and the following frame is exact."""
+def test_default_mode_frame_with_three_times_the_instances_is_exact(tile_local, monkeypatch):
+    """DEFAULT mode: scene A (small splats) then scene B (the same P, W, H, more than 3x the tile instances), images and
+    gradients of B and of a forward-only B against the blocking path, bit for bit, in both binning forms; B's phase 2 must
+    have been repeated (its count exceeded what A had taught the pool)."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _workspace as ws
-    monkeypatch.setattr(ws, "TLO_SETTLE_FRAMES", 0 if tile_local else 1 << 30)
+    monkeypatch.setattr(ws, "_BINNING", "tile" if tile_local else "global")
+    P, W, H = 5000, 160, 96
+    cam = fibonacci_cameras(2, W, H, seed=402)[0]
+    bg = torch.tensor([0.05, 0.0, 0.1])
+    gc, gd = upstream_grads(H, W)
+    b = make_gaussians(P, 3, seed=403, scale_factor=0.9)
+    a = _thinned(b)
+    mode0 = dgr.forward_mode()
+    dgr.set_forward_mode("sync")
+    ref_a = run_hip(a, cam, 3, bg, gc=gc, gd=gd)
+    Ra = dgr.call_stats()["num_rendered"]
+    ref_b = run_hip(b, cam, 3, bg, gc=gc, gd=gd)
+    Rb = dgr.call_stats()["num_rendered"]
+    assert Rb >= 3 * Ra > 0, (Ra, Rb)
+    dgr.set_forward_mode(mode0 if mode0 != "sync" else "exact")
+    assert dgr.forward_mode() in ("exact",)            # what a caller gets without asking for anything
+    pool = ws.pool(torch.device("cuda", 0))
+    pool.forget_estimates()
+    old_min, ws.MIN_CAPACITY = ws.MIN_CAPACITY, 256
+    try:
+        pool.capacity[(P, W, H)] = ws._capacity_for(Ra)    # as if earlier frames of the shape had looked like A
+        for w in pool.free:                                  # fresh buffers of exactly that size: an overrun would corrupt
+            w.binning = w.scratch = None
+        out_a = run_hip(a, cam, 3, bg, gc=gc, gd=gd)
+        n_re = dgr.call_stats()["rerendered_frames"]
+        out_b = run_hip(b, cam, 3, bg, gc=gc, gd=gd)
+        st = dgr.call_stats()
+        assert st["rerendered_frames"] == n_re + 1 and st["num_rendered"] == Rb and st["overflow_frames"] == 0
+        assert pool.capacity[(P, W, H)] >= Rb
+        _same(ref_a, out_a)
+        _same(ref_b, out_b)
+        pool.capacity[(P, W, H)] = ws._capacity_for(Ra)
+        with torch.no_grad():
+            fo = run_hip(b, cam, 3, bg)                      # forward-only: waits for ITS count as well
+        assert torch.equal(fo["color"], ref_b["color"]) and torch.equal(fo["invdepth"], ref_b["invdepth"])
+    finally:
+        ws.MIN_CAPACITY = old_min
+
+
+def _trainer(raw, cams, gts, optimizer="hip_fused"):
+    from scene_utils import GaussianModel, Trainer
+    from gaussian_renderer import render, PipelineParams
+    model = GaussianModel.from_raw(raw.to("cuda"), requires_grad=True)
+    tr = Trainer(model, cams, gts, render, PipelineParams(), torch.zeros(3, device="cuda"), optimizer=optimizer, loss="hip",
+                 separate_sh=True)
+    return model, tr
+
+
+def _model_state(model, tr):
+    out = {n: p.detach().clone() for n, p in zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), model.parameters())}
+    for n, p in zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), model.parameters()):
+        st = tr.optimizer.state.get(p, {})
+        if "exp_avg" in st:
+            out["m_" + n], out["v_" + n] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+    out["accum"], out["denom"], out["maxr"] = model.xyz_gradient_accum.clone(), model.denom.clone(), model.max_radii2D.clone()
+    return out
+
+
+@pytest.mark.parametrize("tile_local", [False, True])
+def test_training_step_after_an_instance_jump_default_and_async(tile_local, monkeypatch):
+    """One training step (render + fused loss + backward with the optimizer folded in + statistics) on a frame with > 3x the
+    instances the shape had shown: parameters, both moments and the densification statistics against the blocking mode, bit for
+    bit - in the DEFAULT mode directly, and in "async" mode after the Trainer has run the truncated view again; the truncated
+    async step itself must leave every one of those tensors bit-unchanged."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _workspace as ws
+    from scene_utils import GaussianModel
+    from gaussian_renderer import render, PipelineParams
+    monkeypatch.setattr(ws, "_BINNING", "tile" if tile_local else "global")
+    P, W, H = 5000, 160, 96
+    cams = fibonacci_cameras(2, W, H, seed=412)
+    for c in cams:
+        c.to("cuda")
+    big = make_gaussians(P, 3, seed=413, scale_factor=0.9)
+    small = _thinned(big)
+    bg = torch.zeros(3, device="cuda")
+    pipe = PipelineParams()
+    with torch.no_grad():
+        teacher = GaussianModel.from_raw(make_gaussians(P, 3, seed=414, scale_factor=1.0).to("cuda"), requires_grad=False)
+        gts = {v: render(cams[v], teacher, pipe, bg)["render"].clamp(0, 1).clone() for v in range(2)}
+        small_model = GaussianModel.from_raw(small.to("cuda"), requires_grad=False)
+    pool = ws.pool(torch.device("cuda", 0))
+    key = (P, W, H)
+
+    def taught_by_small_frames():
+        """the pool as frames of the small-splat scene leave it"""
+        pool.forget_estimates()
+        for w in pool.free:
+            w.binning = w.scratch = None
+        with torch.no_grad():
+            render(cams[0], small_model, pipe, bg)
+        dgr.call_stats()
+        return pool.capacity[key]
+
+    old_min, ws.MIN_CAPACITY = ws.MIN_CAPACITY, 256
+    try:
+        # blocking reference: two steps
+        dgr.set_forward_mode("sync")
+        model, tr = _trainer(big, cams, gts)
+        init = _model_state(model, tr)
+        tr.step(0)
+        ref1 = _model_state(model, tr)
+        Rb = dgr.call_stats()["num_rendered"]
+        tr.step(1)
+        ref2 = _model_state(model, tr)
+
+        # DEFAULT mode
+        dgr.set_forward_mode("exact")
+        cap = taught_by_small_frames()
+        assert Rb >= 3 * cap / ws.HEADROOM, (Rb, cap)
+        model, tr = _trainer(big, cams, gts)
+        n_re = dgr.call_stats()["rerendered_frames"]
+        tr.step(0)
+        got = _model_state(model, tr)
+        assert dgr.call_stats()["rerendered_frames"] == n_re + 1
+        for k in ref1:
+            assert torch.equal(got[k], ref1[k]), k
+        tr.step(1)
+        got = _model_state(model, tr)
+        for k in ref2:
+            assert torch.equal(got[k], ref2[k]), k
+
+        # "async": the truncated step is a no-op, is reported, and the Trainer runs the view again
+        dgr.set_forward_mode("async")
+        taught_by_small_frames()
+        model, tr = _trainer(big, cams, gts)
+        with pytest.warns(RuntimeWarning, match="truncated"):
+            tr.step(0)
+            torch.cuda.synchronize()
+            unchanged = _model_state(model, tr)
+            for k, v in init.items():
+                assert torch.equal(unchanged[k], v), k
+            for k in unchanged:
+                if k[:2] in ("m_", "v_"):
+                    assert not unchanged[k].any(), k
+            assert dgr.call_stats()["overflow_frames"] >= 1
+            tr.finish()                                       # -> _rerun_truncated_frames(wait=True)
+        assert tr.rerun_views == 1
+        got = _model_state(model, tr)
+        for k in ref1:
+            assert torch.equal(got[k], ref1[k]), k
+        tr.step(1)
+        tr.finish()
+        got = _model_state(model, tr)
+        for k in ref2:
+            assert torch.equal(got[k], ref2[k]), k
+    finally:
+        ws.MIN_CAPACITY = old_min
+
+
+@pytest.mark.parametrize("tile_local", [False, True])
+def test_async_capacity_overflow_is_contained_reported_and_heals(tile_local, monkeypatch):
+    """"async" with a capacity far below the instance count: the frame renders from a truncated list (nearest-first in the
+    global binning form, lowest ids first in the tile-local form) without touching memory outside its buffers, every gradient
+    of its backward is an exact zero, the overflow is counted and reported by ticket, the capacity is raised, and the
+    following frame is exact."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _workspace as ws
+    monkeypatch.setattr(ws, "_BINNING", "tile" if tile_local else "global")
     raw, cams = _views(n=2, P=5000, W=160, H=96)
     bg = torch.zeros(3)
     gc, gd = upstream_grads(96, 160)
@@ -70,45 +268,65 @@ def test_async_capacity_overflow_is_contained_and_heals(tile_local, monkeypatch)
         for w in pool.free:                                # fresh buffers of exactly that size: an overrun would fault / corrupt
             w.binning = w.scratch = None
         n0 = dgr.call_stats()["overflow_frames"]
-        out = run_hip(raw, cams[0], 3, bg, gc=gc, gd=gd)
-        st = dgr.call_stats()
+        dgr.take_overflowed()
+        with pytest.warns(RuntimeWarning, match="truncated"):
+            out = run_hip(raw, cams[0], 3, bg, gc=gc, gd=gd)
+            ticket = dgr.last_ticket()
+            st = dgr.call_stats()
         assert st["overflow_frames"] == n0 + 1 and st["num_rendered"] == R
+        assert dgr.take_overflowed() == [ticket] and dgr.take_overflowed() == []
         assert pool.capacity[key] >= R
-        assert torch.isfinite(out["color"]).all() and all(torch.isfinite(g).all() for g in out["grads"].values())
+        assert torch.isfinite(out["color"]).all() and float(out["color"].min()) >= 0.0
         assert torch.equal(out["radii"], ref["radii"])     # per-Gaussian outputs do not depend on the binning capacity
-        # transmittance can only be higher with instances missing: a black background never gets brighter than the reference
-        # by more than rounding... (colour is not monotone per channel, so only sanity-check the range)
-        assert float(out["color"].min()) >= 0.0
+        for k, g in out["grads"].items():                  # nothing is learnt from a truncated frame
+            assert not g.any(), k
         again = run_hip(raw, cams[0], 3, bg, gc=gc, gd=gd)
         assert dgr.call_stats()["overflow_frames"] == n0 + 1
-        assert torch.equal(again["color"], ref["color"])
-        for k in ref["grads"]:
-            assert torch.equal(again["grads"][k], ref["grads"][k]), k
+        _same(ref, again)
     finally:
         ws.MIN_CAPACITY = old_min
 
 
-@pytest.mark.parametrize("tlo,pinned", [(0, True), (1, True), (1, False)])
-def test_lowlevel_async_call_matches_blocking_state(tlo, pinned):
-    """The C ABI directly: gsr_forward_async with a generous capacity - in both binning forms (tlo = 1: emission in index
-    order + per-tile depth ordering in LDS) - leaves the same images, the same sorted lists (first num_rendered entries) and the
-    same tile ranges as the blocking calls.  The status words reach a pinned slot through the compositing kernel's own store
-    and pageable memory through a copy."""
-    import ctypes as C
-    import math
-    from diff_gaussian_rasterization import _C, GaussianRasterizationSettings, _settings_struct, _gauss_struct, _stream
-    from helpers import settings_for, leaf_inputs, lowlevel_forward, _view
-    raw, cams = _views(n=1, P=4000, W=176, H=112)
+def _lowlevel_setup(P=4000, W=176, H=112):
+    from diff_gaussian_rasterization import _C, GaussianRasterizationSettings, _settings_struct, _gauss_struct
+    from helpers import settings_for, leaf_inputs, lowlevel_forward
+    raw, cams = _views(n=1, P=P, W=W, H=H)
     cam, bg = cams[0], torch.tensor([0.1, 0.1, 0.1])
     a = lowlevel_forward(raw, cam, 3, bg)
     lib = _C.lib()
     dev = "cuda"
     inp = leaf_inputs(raw, torch.float32, dev, "sh")
-    P, H, W = 4000, cam.image_height, cam.image_width
     rs = settings_for(cam, 3, bg, 1.0, False, cls=GaussianRasterizationSettings, device=dev)
     s, keep = _settings_struct(rs, dev)
     t = {k: v.detach().contiguous() for k, v in inp.items()}
     g = _gauss_struct(P, t["means3D"], None, t["shs"], None, t["opacities"], t["scales"], t["rotations"], None)
+    return a, lib, s, g, (keep, t, inp, rs)
+
+
+def _check_state(lib, a, binning, cap, W, H, color, invd, radii):
+    from diff_gaussian_rasterization import _C
+    from helpers import _view
+    assert torch.equal(color.cpu(), a["color"]) and torch.equal(invd.cpu(), a["invdepth"]) and torch.equal(radii.cpu(), a["radii"])
+    pb = [C.c_void_p() for _ in range(2)]
+    lib.gsr_debug_binning_views(_C.ptr(binning), W, H, cap, C.byref(pb[0]), C.byref(pb[1]))
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    pl = _view(binning, pb[0].value, a["R"], torch.int32).numpy().view("uint32")
+    rg = _view(binning, pb[1].value, tiles * 2, torch.int32).numpy().view("uint32").reshape(tiles, 2)
+    assert (pl == a["point_list"]).all() and (rg == a["ranges"]).all()
+    return rg
+
+
+@pytest.mark.parametrize("tlo,pinned,verify", [(0, True, False), (1, True, False), (1, False, False), (0, True, True),
+                                               (1, True, True)])
+def test_lowlevel_async_call_matches_blocking_state(tlo, pinned, verify):
+    """The C ABI directly: gsr_forward_async with a generous capacity - in both binning forms (tlo = 1: emission in index
+    order + per-tile depth ordering in LDS) - leaves the same images, the same sorted lists (first num_rendered entries) and the
+    same tile ranges as the blocking calls.  The status words reach a pinned slot through the compositing kernel's own store
+    and pageable memory through a copy; with `num_rendered_out` the call itself returns the count."""
+    from diff_gaussian_rasterization import _C, _stream
+    P, W, H = 4000, 176, 112
+    a, lib, s, g, keep = _lowlevel_setup(P, W, H)
+    dev = "cuda"
     cap = int(a["R"] * 1.5) + 1000
     geom = torch.zeros(lib.gsr_geometry_state_bytes(P), dtype=torch.uint8, device=dev)
     img = torch.zeros(lib.gsr_image_state_bytes(W, H), dtype=torch.uint8, device=dev)
@@ -118,28 +336,56 @@ def test_lowlevel_async_call_matches_blocking_state(tlo, pinned):
     status = torch.zeros(4, dtype=torch.int64)
     if pinned:
         status = status.pin_memory()
+    count = C.c_int64(-1)
     _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii), _C.ptr(binning),
                                    binning.numel(), cap, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invd), 1, 0, None,
-                                   C.c_void_p(status.data_ptr()), tlo, _stream()))
+                                   C.c_void_p(status.data_ptr()), tlo, _stream(), C.byref(count) if verify else None))
+    if verify:
+        assert count.value == a["R"]                     # known before the device has finished the frame
     torch.cuda.synchronize()
     assert int(status[1]) == a["R"]
-    assert torch.equal(color.cpu(), a["color"]) and torch.equal(invd.cpu(), a["invdepth"]) and torch.equal(radii.cpu(), a["radii"])
-    pb = [C.c_void_p() for _ in range(2)]
-    lib.gsr_debug_binning_views(_C.ptr(binning), W, H, cap, C.byref(pb[0]), C.byref(pb[1]))
-    tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    pl = _view(binning, pb[0].value, a["R"], torch.int32).numpy().view("uint32")
-    rg = _view(binning, pb[1].value, tiles * 2, torch.int32).numpy().view("uint32").reshape(tiles, 2)
-    assert (pl == a["point_list"]).all() and (rg == a["ranges"]).all()
+    rg = _check_state(lib, a, binning, cap, W, H, color, invd, radii)
     if tlo:      # the longest tile list is reported once it passes half the LDS capacity of the per-tile sort (else 0)
         longest = int((rg[:, 1] - rg[:, 0]).max())
         assert int(status[2]) & 0xFFFFFFFF == (longest if longest > 2048 else 0)
 
 
-def test_parity_suite_with_the_other_backward_form_and_blocking_forward():
+@pytest.mark.parametrize("tlo", [0, 1])
+def test_lowlevel_verified_overflow_then_rerender_matches_blocking_state(tlo):
+    """gsr_forward_async(num_rendered_out) with a third of the needed capacity reports the true count; gsr_forward_rerender on a
+    binning state that holds it then leaves exactly the blocking path's images, lists and ranges."""
+    from diff_gaussian_rasterization import _C, _stream
+    P, W, H = 4000, 176, 112
+    a, lib, s, g, keep = _lowlevel_setup(P, W, H)
+    dev = "cuda"
+    small = max(256, a["R"] // 3)
+    geom = torch.zeros(lib.gsr_geometry_state_bytes(P), dtype=torch.uint8, device=dev)
+    img = torch.zeros(lib.gsr_image_state_bytes(W, H), dtype=torch.uint8, device=dev)
+    binning = torch.zeros(lib.gsr_binning_state_bytes(P, W, H, small), dtype=torch.uint8, device=dev)
+    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    color, invd = torch.empty(3, H, W, device=dev), torch.empty(1, H, W, device=dev)
+    status = torch.zeros(4, dtype=torch.int64).pin_memory()
+    count = C.c_int64(-1)
+    _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii), _C.ptr(binning),
+                                   binning.numel(), small, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invd), 1, 0, None,
+                                   C.c_void_p(status.data_ptr()), tlo, _stream(), C.byref(count)))
+    assert count.value == a["R"] > small
+    cap = a["R"] + 17
+    big = torch.zeros(lib.gsr_binning_state_bytes(P, W, H, cap), dtype=torch.uint8, device=dev)
+    _C.check(lib.gsr_forward_rerender(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(big), big.numel(), cap, _C.ptr(img),
+                                      img.numel(), _C.ptr(color), _C.ptr(invd), 1, tlo, C.c_void_p(status.data_ptr()),
+                                      _stream()))
+    torch.cuda.synchronize()
+    assert int(status[1]) == a["R"]
+    _check_state(lib, a, big, cap, W, H, color, invd, radii)
+
+
+def test_parity_suite_with_the_other_backward_form_and_other_forward_modes():
     """The two forms of the compositing backward (one wave per tile from 6000 tiles up, four waves per tile below) are chosen by
     image size, so the small-image parity tests only ever see the four-wave form.  Re-run the core parity tests in a child
-    process with GSR_BWD_FORM=tile (two parity modes, edge cases, bitwise repeat, committed golden), and once
-    more with the blocking forward (GSR_FORWARD_MODE=sync) and the colour pass kept on the caller's stream."""
+    process with GSR_BWD_FORM=tile and the unverified forward (GSR_FORWARD_MODE=async; two parity modes, edge cases, bitwise
+    repeat, committed golden), and once more with the blocking forward (GSR_FORWARD_MODE=sync), the global binning form and the
+    colour pass on the side stream."""
     import os
     import subprocess
     import sys
@@ -149,8 +395,9 @@ def test_parity_suite_with_the_other_backward_form_and_blocking_forward():
     par = "tests/test_parity_gpu.py::test_forward_backward_parity"
     sel = [par + "[sh-True-False]", par + "[colors-True-True]", "tests/test_parity_gpu.py::test_edge_cases",
            "tests/test_parity_gpu.py::test_bitwise_reproducible", "tests/test_parity_gpu.py::test_against_committed_golden"]
-    for extra, tests in (({"GSR_BWD_FORM": "tile", "GSR_TLO_SETTLE": "0"}, sel),      # + tile-local binning from frame 2 on
-                         ({"GSR_BWD_FORM": "quad", "GSR_FORWARD_MODE": "sync", "GSR_SHADE_STREAM": "1"}, sel[1:4])):
+    for extra, tests in (({"GSR_BWD_FORM": "tile", "GSR_FORWARD_MODE": "async"}, sel),
+                         ({"GSR_BWD_FORM": "quad", "GSR_FORWARD_MODE": "sync", "GSR_SHADE_STREAM": "1"}, sel[1:4]),
+                         ({"GSR_BINNING": "global", "GSR_SHADE_STREAM": "1"}, sel[2:4])):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + tests, cwd=root, env=env,
                            capture_output=True, text=True, timeout=900)
@@ -158,7 +405,7 @@ def test_parity_suite_with_the_other_backward_form_and_blocking_forward():
 
 
 @pytest.mark.parametrize("P", [9000, 2600])
-def test_tile_local_sort_long_lists_and_policy(P, monkeypatch):
+def test_tile_local_sort_long_lists_and_policy(P):
     """Every Gaussian piled onto the image centre.  P = 9000: tile lists of > 4096 entries take k_tile_depth_sort's in-memory
     path, and the Python policy (tile-local form first, back to the global form once a shape has shown lists beyond 3072
     entries) switches.  P = 2600: lists between 1024 and 3072 entries - the second launch of the LDS sort - and no switch.
@@ -167,18 +414,18 @@ def test_tile_local_sort_long_lists_and_policy(P, monkeypatch):
     from diff_gaussian_rasterization import _workspace as ws
     if ws._BINNING != "tile":
         pytest.skip("GSR_BINNING=global")
-    monkeypatch.setattr(ws, "TLO_SETTLE_FRAMES", 0)   # (normally the form waits until the shape's capacity has held 3 frames)
     raw = make_gaussians(P, 1, seed=511, scale_factor=0.5)
     raw.xyz *= 0.02                                   # a 5 cm blob at the origin: every splat covers the central tiles
     cam = fibonacci_cameras(2, 96, 64, seed=512)[0]
     bg = torch.tensor([0.0, 0.1, 0.0])
     gc, gd = upstream_grads(64, 96)
+    mode = dgr.forward_mode()
     dgr.set_forward_mode("sync")
     ref = run_hip(raw, cam, 1, bg, gc=gc, gd=gd)
-    dgr.set_forward_mode("async")
+    dgr.set_forward_mode("exact" if mode == "sync" else mode)
     pool = ws.pool(torch.device("cuda", 0))
     key = (P, 96, 64)
-    pool.longest_list.pop(key, None)
+    pool.forget_estimates()
     n0 = pool.stats.get("tile_local_frames", 0)
     for it in range(4):
         out = run_hip(raw, cam, 1, bg, gc=gc, gd=gd)

@@ -58,16 +58,16 @@ def _check_sampled(ref, out, mask, W, H, depth=True, ref32=None):
 
 
 def _tile_local_frame_equals(out, run, monkeypatch):
-    """The same frame through the tile-local binning form (no global depth sort; normally entered once a shape's capacity has
-    held for three frames): bit-identical images and gradients at full size."""
+    """The same frame through the OTHER binning form (`out` came through the default, tile-local one - no global depth sort;
+    the global form is the blocking path's): bit-identical images and gradients at full size."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _workspace as ws
     if ws._BINNING != "tile":
         return
-    monkeypatch.setattr(ws, "TLO_SETTLE_FRAMES", 0)
+    monkeypatch.setattr(ws, "_BINNING", "global")
     n0 = dgr.call_stats().get("tile_local_frames", 0)
     again = run()
-    assert dgr.call_stats().get("tile_local_frames", 0) == n0 + 1
+    assert dgr.call_stats().get("tile_local_frames", 0) == n0
     assert torch.equal(out["color"], again["color"]) and torch.equal(out["invdepth"], again["invdepth"])
     for k in out["grads"]:
         assert torch.equal(out["grads"][k], again["grads"][k]), k

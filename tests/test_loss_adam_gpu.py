@@ -1,12 +1,12 @@
 """GPU parity of the two callers of the hot path that the reference also takes from native modules:
-fused SSIM (oracle: the pure-PyTorch ssim() restated in scene_utils/losses.py, itself pinned against the reference's
+fused SSIM (oracle: the pure-PyTorch ssim() restated in oracle/loss_oracle.py, itself pinned against the reference's
 utils/loss_utils.py:ssim by tests/golden/reference_helpers.npz) and the one-launch Adam kernels (oracle: torch.optim.Adam
 on CPU; the sparse variant against a masked no-bias-correction restatement)."""
 import numpy as np
 import pytest
 import torch
 
-from scene_utils import losses
+from oracle import loss_oracle as losses
 
 pytestmark = pytest.mark.gpu
 

