@@ -259,7 +259,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                     status[2] = 0
                     tlo = 1 if _ws.tile_local_binning(pool, key) else 0
                     count = C.c_int64(-1)
-                    verify = mode == "exact"
+                    verify = mode == "exact" or key not in pool.capacity     # ("async": a shape's first frame is verified too -
+                    #                                                           its capacity is a guess, not an observation)
                     _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
                                                    _C.ptr(binning), binning.numel(), R, _C.ptr(img), img.numel(),
                                                    _C.ptr(color), _C.ptr(invdepth), 1 if needs_grad else 0,
@@ -280,9 +281,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                               _C.ptr(invdepth), 1 if needs_grad else 0, tlo,
                                                               C.c_void_p(status.data_ptr()), stream))
                         pool.note(key, n)
-                        pool.stats["exact_frames"] += 1
-                    else:
-                        pool.stats["async_frames"] += 1
+                    pool.stats["exact_frames" if mode == "exact" else "async_frames"] += 1
                     done = torch.cuda.Event()
                     done.record()
                     pool.pending.append((done, status, R, key, pool.ticket, verify))
