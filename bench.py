@@ -145,11 +145,10 @@ def kernel_table(prof, R, N, P, M):
         # colour pass in its own kernel (side stream): the projection kernel no longer reads the SH rows or writes colours
         alg["preprocess_fwd"] = P * (44 + 75)
         alg["shade"] = P * (12 * M + 12 + 16 + 1)          # SH row + mean in; colour part of the record + clamp flags out
-    if "tile_gather_sort" in prof:
-        # bucket form of the binning stage: per instance one byte key (read once from HBM, the other tiles of the bucket read
-        # it from L2), Gaussian id + depth key + emission slot gathered, list entry + slot written; the bucket sort's pass(es)
-        # run on the R instances
-        alg["tile_gather_sort"] = 21 * R
+    if "tile_depth_sort" in prof:
+        # tile-local binning form: list entry + its depth key in, (entry, emission slot) re-read through the permutation and
+        # written back; the tile sort's passes all run on the R instances
+        alg["tile_depth_sort"] = 28 * R
         alg["radix_hist"] = 4 * R
         alg["emit_instances"] = 40 * P + 8 * R
     out = {}

@@ -22,11 +22,9 @@ int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const i
                               const GsrGeomLayout&, const float4*, uint32_t, const gsr_grads*, const GsrAdamArgs*, int,
                               hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
-void gsr_launch_emit(int, int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, bool, uint32_t*,
-                     uint32_t*, hipStream_t);
-void gsr_launch_tile_gather_sort(int, bool, const uint32_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*,
-                                 uint32_t*, uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, const uint32_t*,
-                                 uint32_t, hipStream_t);
+void gsr_launch_emit(int, int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, bool, hipStream_t);
+void gsr_launch_tile_depth_sort(int, bool, const uint2*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*,
+                                uint32_t*, hipStream_t);
 void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
@@ -189,6 +187,12 @@ static int tile_bits(int tiles) {
   int b = 1;
   while ((1 << b) < tiles) b++;
   return b;
+}
+// which ping-pong buffer holds the tile-sorted (key, slot) arrays: one swap per 8-bit pass
+static int tile_sort_result_buffer(int tiles) { return gsr_radix_passes(tile_bits(tiles)) & 1; }
+// the Gaussian-id list rides through the tile sort as a second payload, ping-ponging gauss_of_slot <-> point_list
+static size_t point_list_offset(const GsrBinLayout& BL, int tiles) {
+  return tile_sort_result_buffer(tiles) ? BL.point_list : BL.gauss_of_slot;
 }
 
 static int validate(const gsr_settings* s, const gsr_gaussians* g) {
@@ -451,19 +455,7 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   if (R == 0 || g->P == 0) {   // nothing to emit: every tile range is empty (otherwise the emit kernel clears them on its way)
     if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
   } else {
-    // The tile sort ping-pongs between the array sets X and F (gsr_common.h).  The FINAL lists always live in F (gid_f, val_f):
-    // the global form sorts straight into F, the bucket form sorts into X and its per-tile kernel writes F - so the emission
-    // starts in whichever set the parity of the passes asks for.
-    const int bshift = gsr_bucket_shift(tiles), bbits = gsr_bits_for(gsr_bucket_count(tiles));
-    const int passes = gsr_radix_passes(tile_local ? bbits : tile_bits(tiles));
-    const bool start_in_f = tile_local ? (passes & 1) != 0 : (passes & 1) == 0;
-    uint32_t* k0 = (uint32_t*)(bin + (start_in_f ? BL.key_f : BL.key_x));
-    uint32_t* k1 = (uint32_t*)(bin + (start_in_f ? BL.key_x : BL.key_f));
-    uint32_t* s0 = (uint32_t*)(bin + (start_in_f ? BL.val_f : BL.val_x));
-    uint32_t* s1 = (uint32_t*)(bin + (start_in_f ? BL.val_x : BL.val_f));
-    uint32_t* g0 = (uint32_t*)(bin + (start_in_f ? BL.gid_f : BL.gid_x));
-    uint32_t* g1 = (uint32_t*)(bin + (start_in_f ? BL.gid_x : BL.gid_f));
-    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, k0, g0, st);
+    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, st);
     {
       SideShade* a = (tile_local && !shade_late && sh_ready) ? side_shade() : nullptr;
       if (a && sh_ready == a->join) {      // colour pass on the side stream, beside the tile sort (see forward_geometry)
@@ -476,35 +468,33 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
     if ((rc = debug_sync(s, st, "emit instances"))) return rc;
     // With a backward to follow, the sort carries (emission slot, Gaussian id): the slot of every list position is where the
     // backward stores that instance's gradient record.  A forward-only render (torch.no_grad) needs the ids alone: they
-    // become the one sorted value, 8 B less per key and pass.
-    uint32_t* tmp = (uint32_t*)(bin + BL.radix_tmp);
-    if (!tile_local) {
-      const int where = for_backward ? gsr_radix_sort_pairs(k0, s0, k1, s1, /*vals_iota=*/true, R, tile_bits(tiles), tmp, st, g0, g1,
-                                                            n_dev, /*head_zeroed (by the emit kernel)=*/true)
-                                     : gsr_radix_sort_pairs(k0, g0, k1, g1, /*vals_iota=*/false, R, tile_bits(tiles), tmp, st,
-                                                            nullptr, nullptr, n_dev, true);
-      if ((where ? k1 : k0) != (uint32_t*)(bin + BL.key_f)) { gsr_set_error("internal: tile sort buffer parity"); return GSR_ERR_HIP; }
-      if ((rc = debug_sync(s, st, "tile sort"))) return rc;
-      gsr_launch_finalize((uint32_t)R, n_dev, (const uint32_t*)(bin + BL.key_f), bin, BL, st);
-      if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
-    } else {
-      // bucket form (binning.hip): ONE stable pass by bucket (two beyond 256 buckets) that leaves a byte key per instance, then
-      // every tile collects and depth-orders its own list and writes it (and its range) to the final arrays
-      uint32_t* bhist = passes == 1 ? tmp /* the pass's own digit histogram */ : (uint32_t*)(bin + BL.bucket_hist);
-      uint8_t* bkey8 = (uint8_t*)(bin + BL.bkey8);
-      const int where = for_backward ? gsr_radix_sort_pairs(k0, s0, k1, s1, true, R, bbits, tmp, st, g0, g1, n_dev, true, bshift,
-                                                            bkey8, bhist)
-                                     : gsr_radix_sort_pairs(k0, g0, k1, g1, false, R, bbits, tmp, st, nullptr, nullptr, n_dev, true,
-                                                            bshift, bkey8, bhist);
-      if ((where ? k1 : k0) != (uint32_t*)(bin + BL.key_x)) { gsr_set_error("internal: bucket sort buffer parity"); return GSR_ERR_HIP; }
-      if ((rc = debug_sync(s, st, "bucket sort"))) return rc;
-      gsr_launch_tile_gather_sort(tiles, for_backward, bhist, bkey8, (const uint32_t*)(bin + BL.gid_x),
-                                  for_backward ? (const uint32_t*)(bin + BL.val_x) : nullptr,
-                                  (const uint32_t*)(geom + GL.depth_key), (uint32_t*)(bin + BL.gid_f),
-                                  for_backward ? (uint32_t*)(bin + BL.val_f) : nullptr, (uint2*)(bin + BL.ranges),
-                                  (uint32_t*)(bin + BL.tmp_a), (uint32_t*)(bin + BL.tmp_b), (uint32_t*)(bin + BL.key_f),
-                                  (uint32_t*)(geom + GL.meta), n_dev, (uint32_t)R, st);
-      if ((rc = debug_sync(s, st, "tile gather + depth sort"))) return rc;
+    // become the one sorted value (same ping-pong parity, so the list ends up in the same place), 8 B less per key and pass.
+    const int where =
+        for_backward
+            ? gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a), (uint32_t*)(bin + BL.key_b),
+                                   (uint32_t*)(bin + BL.val_b), /*vals_iota=*/true, R, tile_bits(tiles),
+                                   (uint32_t*)(bin + BL.radix_tmp), st, (uint32_t*)(bin + BL.gauss_of_slot),
+                                   (uint32_t*)(bin + BL.point_list), n_dev, /*head_zeroed (by the emit kernel)=*/true)
+            : gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
+                                   (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.point_list), /*vals_iota=*/false, R,
+                                   tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st, nullptr, nullptr, n_dev, true);
+    if (where != tile_sort_result_buffer(tiles)) { gsr_set_error("internal: tile sort buffer parity"); return GSR_ERR_HIP; }
+    if ((rc = debug_sync(s, st, "tile sort"))) return rc;
+    const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
+    gsr_launch_finalize((uint32_t)R, n_dev, ks, bin, BL, st);
+    if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
+    if (tile_local) {
+      // every tile orders its own list by (depth bits, id); the free halves of the tile sort's ping-pong buffers serve the
+      // (slow) path for lists beyond the LDS capacity
+      uint32_t* free_k = (uint32_t*)(bin + (where ? BL.key_a : BL.key_b));
+      uint32_t* free_w = (uint32_t*)(bin + (where ? BL.gauss_of_slot : BL.point_list));
+      uint32_t* free_v = (uint32_t*)(bin + (for_backward ? (where ? BL.val_a : BL.val_b) : BL.val_a));
+      uint32_t* slots = for_backward ? (uint32_t*)(bin + (where ? BL.val_b : BL.val_a)) : nullptr;
+      gsr_launch_tile_depth_sort(tiles, for_backward, (const uint2*)(bin + BL.ranges),
+                                 (uint32_t*)(bin + point_list_offset(BL, tiles)), slots,
+                                 (const uint32_t*)(geom + GL.depth_key), free_k, free_v, free_w,
+                                 (uint32_t*)(geom + GL.meta), st);
+      if ((rc = debug_sync(s, st, "tile depth sort"))) return rc;
     }
   }
   // status words of the non-blocking forward: written by the compositing kernel itself when the caller's slot is pinned
@@ -523,7 +513,7 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
     gsr_launch_shade(s, g, geom, GL, false, st);
     if ((rc = debug_sync(s, st, "shade"))) return rc;
   }
-  gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + BL.gid_f),
+  gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                         (const float4*)(geom + GL.rec), out_color, out_invdepth, (float*)(img + IL.final_T),
                         (uint32_t*)(img + IL.n_contrib), status_dev ? (const uint32_t*)(geom + GL.meta) : nullptr, status_dev,
                         st);
@@ -553,9 +543,7 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
                       void* stream, int64_t* num_rendered_out) {
   int rc = validate(s, g);
   if (rc) return rc;
-  // (the bucket form takes images of up to 131072 tiles, gsr_common.h; larger ones silently use the global form)
-  const bool tlo = tile_local_sort != 0 &&
-                   gsr_bucket_form_ok(((s->image_width + GSR_TILE - 1) / GSR_TILE) * ((s->image_height + GSR_TILE - 1) / GSR_TILE));
+  const bool tlo = tile_local_sort != 0;
   if (num_rendered_out) *num_rendered_out = 0;
   if (g->P > 0) {
     const bool late = defer_color != 0 && !g->colors_precomp;
@@ -599,12 +587,9 @@ int gsr_forward_rerender(const gsr_settings* s, const gsr_gaussians* g, void* ge
                          void* stream) {
   // everything phase 2 reads of the geometry state - records with their colours, tile counts, the count itself, depth order
   // or per-workgroup start slots - was left complete by the gsr_forward_async call this one repairs
-  int rc = validate(s, g);
-  if (rc) return rc;
-  const bool tlo = tile_local_sort != 0 &&
-                   gsr_bucket_form_ok(((s->image_width + GSR_TILE - 1) / GSR_TILE) * ((s->image_height + GSR_TILE - 1) / GSR_TILE));
   return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
-                             out_color, out_invdepth, for_backward != 0, false, nullptr, stream, tlo, host_status);
+                             out_color, out_invdepth, for_backward != 0, false, nullptr, stream, tile_local_sort != 0,
+                             host_status);
 }
 
 static int adam_args(const gsr_gaussians* g, const gsr_fused_adam* opt, GsrAdamArgs& A) {
@@ -662,10 +647,10 @@ static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const in
   const char* img = (const char*)image_state;
   float4* igrad = (float4*)scratch;
   if (R > 0) {
-    gsr_launch_render_bwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + BL.gid_f),
+    gsr_launch_render_bwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                           (const float4*)(geom + GL.rec), (const float*)(img + IL.final_T),
                           (const uint32_t*)(img + IL.n_contrib), dL_dcolor, dL_dinvdepth,
-                          (const uint32_t*)(bin + BL.val_f), igrad,
+                          (const uint32_t*)(bin + (tile_sort_result_buffer(tiles) ? BL.val_b : BL.val_a)), igrad,
                           (const uint32_t*)(geom + GL.meta) + 2, (uint32_t)R, st);
     if ((rc = debug_sync(s, st, "render backward"))) return rc;
   }
@@ -749,7 +734,7 @@ int gsr_debug_binning_views(const void* binning_state, int32_t W, int32_t H, int
   const size_t tiles = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * (size_t)((H + GSR_TILE - 1) / GSR_TILE);
   const GsrBinLayout BL = gsr_bin_layout((size_t)R, tiles);
   const char* bin = (const char*)binning_state;
-  if (point_list) *point_list = (const uint32_t*)(bin + BL.gid_f);
+  if (point_list) *point_list = (const uint32_t*)(bin + point_list_offset(BL, tiles));
   if (ranges) *ranges = (const uint32_t*)(bin + BL.ranges);
   return 0;
 }
@@ -767,7 +752,7 @@ int gsr_debug_count_pairs(const gsr_settings* s, int32_t P, const void* geometry
   const GsrBinLayout BL = gsr_bin_layout((size_t)num_rendered, tiles);
   const char* geom = (const char*)geometry_state;
   const char* bin = (const char*)binning_state;
-  gsr_launch_count_pairs(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + BL.gid_f),
+  gsr_launch_count_pairs(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                          (const float4*)(geom + GL.rec), pairs, (hipStream_t)stream);
   return gsr_launch_status("count_pairs");
 }

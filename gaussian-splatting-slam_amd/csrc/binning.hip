@@ -136,170 +136,52 @@ __global__ __launch_bounds__(256) void k_finalize_bins(uint32_t cap, const uint3
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Bucket form of the binning stage (gsr_forward_async(tile_local_sort = 1)): no global depth order, and NO full sort by tile.
+// Tile-local depth ordering (second form of the binning stage, gsr_forward_async(tile_local_sort = 1)).
 //
 // The first form depth-sorts all P Gaussians (4 radix passes, each paying ~15 us of inter-workgroup coordination at 1 M keys
-// for 16 MB of traffic), scans their tile counts through a gather, emits in depth order and sorts the instances by tile id
-// (two more passes at 1080p), so that the STABLE tile sort leaves every tile's list in (depth, id) order.  Here instances are
-// emitted in INDEX order (coalesced record reads; the tile-count scan collapses into the projection and emission kernels plus
-// one single-workgroup launch) and sorted by BUCKET only - a bucket = 32 consecutive tile ids (gsr_bucket_shift), 255 buckets at
-// 1080p: ONE stable radix pass whose output keeps, per instance, one byte (the tile inside its bucket), the Gaussian id and the
-// emission slot.  Then one workgroup per tile
-//   1. reads its bucket's byte keys (~17 KB at C3, served by the XCD's L2: the 32 tiles of a bucket are mapped to workgroups of
-//      one XCD), four at a time with 7-bit arithmetic, counting the instances of smaller tiles (-> where its list starts: the
-//      tile ranges need no pass of their own) and collecting the positions of its own in bucket order = id order;
-//   2. gathers their Gaussian ids and depth bits and orders them by (depth bits, position) with a stable LSD radix sort in LDS
-//      (8-bit digits, passes whose digit is the same for every key are skipped, ballot ranking like the global sort) - position
-//      = id order, so ties break exactly as in the first form;
-//   3. writes the list (and the emission slots the backward needs) to its final place.
-// ~550 entries per tile at C3.  Lists longer than GSR_TLO_CAP are ordered by a bitonic network in global memory: correct, slow,
-// and reported (meta[4] = longest list) so that the caller goes back to the first form for scenes that need it.  Lists, images
-// and gradients are bit-identical to the first form.
+// for 16 MB of traffic), scans their tile counts through a gather and emits in depth order, so that the STABLE tile sort
+// leaves every tile's list in (depth, id) order.  Here nothing global is ordered by depth: instances are emitted in INDEX
+// order (coalesced record reads; the tile-count scan collapses into the projection and emission kernels plus one
+// single-workgroup launch), the same stable tile sort leaves every list in id order, and one workgroup per tile orders ITS
+// list by (depth bits, position) - position = id order, so ties break exactly as before - with a stable LSD radix sort in
+// LDS, then permutes the list (and the emission slots the backward needs) in place.  ~550 entries per tile at C3.  Lists
+// longer than GSR_TLO_CAP are ordered by a bitonic network in global memory (the two free ping-pong halves of the tile sort
+// hold depth bits and positions): correct, slow, and reported (meta[4] = longest list) so that the caller goes back to the
+// first form for scenes that need it.  Results are bit-identical to the first form.
 // ---------------------------------------------------------------------------------------------------------------
 #define GSR_TLO_CAP 4096
 #define GSR_TLO_SMALL 1024
+#ifndef GSR_TLO_SPLIT
+#define GSR_TLO_SPLIT 1      // lists up to GSR_TLO_SMALL in a launch of their own with a quarter of the LDS (more tiles in flight per CU)
+#endif
 template <bool DUAL, int CAP, int ABOVE>
-__global__ __launch_bounds__(256) void k_tile_gather_sort(int tiles, int bshift, const uint32_t* __restrict__ bucket_hist,
-                                                          const uint8_t* __restrict__ bkey8,
-                                                          const uint32_t* __restrict__ gid_b,
-                                                          const uint32_t* __restrict__ slot_b,
-                                                          const uint32_t* __restrict__ depth_key,
-                                                          uint32_t* __restrict__ point_list,
-                                                          uint32_t* __restrict__ slot_of_pos, uint2* __restrict__ ranges,
-                                                          uint32_t* __restrict__ free_a, uint32_t* __restrict__ free_b,
-                                                          uint32_t* __restrict__ free_c, uint32_t* __restrict__ meta,
-                                                          const uint32_t* __restrict__ n_dev, uint32_t cap) {
+__global__ __launch_bounds__(256) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
+                                                         uint32_t* __restrict__ slot_of_pos,
+                                                         const uint32_t* __restrict__ depth_key, uint32_t* __restrict__ free_a,
+                                                         uint32_t* __restrict__ free_b, uint32_t* __restrict__ free_c,
+                                                         uint32_t* __restrict__ meta) {
+  // LDS path: stable LSD radix sort of the list's 32-bit depth keys (8-bit digits, passes whose digit is the same for every
+  // key are skipped - the keys of one tile usually differ in their low ~20 bits only), ranked like the global sort: each
+  // wave ranks a contiguous quarter of the list with ballots and wave-private counters.  The position in the id-ordered
+  // input rides along, so equal depths keep ascending id.  Linear in the list length (a bitonic network on the same data
+  // moved 20x the bytes through LDS and took 0.17 ms per frame at C3).
   __shared__ uint32_t skey[CAP];                   // one buffer: a pass reads its elements into registers, then scatters
   __shared__ uint16_t sidx[CAP];
-  __shared__ uint32_t mpos[CAP];                   // position inside the bucket of the tile's k-th instance (id order)
   __shared__ uint32_t wave_run[4][256];
   __shared__ uint32_t dstart[256];
-  __shared__ uint32_t red[8], scan4[4];
+  __shared__ uint32_t red[4], scan4[4];
+  const uint2 range = ranges[blockIdx.x];
+  const uint32_t x = range.x, n = range.y - range.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // workgroups b and b + 8 share an XCD (round-robin dispatch; a speed assumption only): give each XCD whole buckets, so a
-  // bucket's keys are read from HBM once and from that XCD's L2 by the other tiles
-  const int B = 1 << bshift, nb = (tiles + B - 1) >> bshift;
-  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int bucket = (seq >> bshift) * 8 + xcd, t_in = seq & (B - 1);
-  const int tile = (bucket << bshift) + t_in;
-  if (bucket >= nb || tile >= tiles) return;        // block-uniform
-  if (ABOVE > 0) {                                  // second launch: only the lists the first one left (its ranges are final)
-    const uint2 r = ranges[tile];
-    if (r.y - r.x <= (uint32_t)ABOVE) return;
-  }
-  // ---- where the bucket lies: instances of all earlier buckets ----
-  uint32_t bs, be;
-  {
-    uint32_t v = 0;
-    for (int i = tid; i < bucket; i += 256) v += bucket_hist[i];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    if (lane == 0) red[w] = v;
-    __syncthreads();
-    const uint32_t n_eff = gsr_eff_n(n_dev, cap);
-    bs = (red[0] + red[1]) + (red[2] + red[3]);
-    be = bs + bucket_hist[bucket];
-    bs = min(bs, n_eff);                            // (a frame beyond the capacity lost its last buckets, never memory safety)
-    be = min(be, n_eff);
-  }
-  // ---- pass 1 over the bucket's keys: instances of smaller tiles, instances of this tile ----
-  const uint32_t a0 = bs & ~15u;                    // the key array is 256-B aligned: 16-B pieces from a0
-  const uint32_t np = (be > a0) ? ((be - a0 + 15u) >> 4) : 0u;
-  const uint32_t ppt = (np + 255u) >> 8;            // pieces per thread, contiguous: thread order = position order
-  const uint32_t p0 = min(np, (uint32_t)tid * ppt), p1 = min(np, p0 + ppt);
-  const uint32_t trep = (uint32_t)t_in * 0x01010101u, grep = (uint32_t)(0x80 - t_in) * 0x01010101u;
-  const uint4* kp = reinterpret_cast<const uint4*>(bkey8 + a0);
-  // per word: 0x80 in every byte that equals t_in / is smaller than t_in (keys are < 128: no carry between bytes)
-  auto eq_bits = [&](uint32_t x) __attribute__((always_inline)) {
-    return ~(((x & 0x7F7F7F7Fu) ^ trep) + 0x7F7F7F7Fu) & 0x80808080u;
-  };
-  auto lt_bits = [&](uint32_t x) __attribute__((always_inline)) { return ~((x & 0x7F7F7F7Fu) + grep) & 0x80808080u; };
-  // bytes of piece p that belong to the bucket, as 0x80 marks per word
-  auto valid_bits = [&](uint32_t p, uint32_t* vb) __attribute__((always_inline)) {
-    const uint32_t g0 = a0 + 16u * p;
-    const uint32_t lo = bs > g0 ? bs - g0 : 0u, hi = min(16u, be - g0);
-    const uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t m = (vm >> (4 * j)) & 15u;
-      vb[j] = ((m & 1u) << 7) | ((m & 2u) << 14) | ((m & 4u) << 21) | ((m & 8u) << 28);
-    }
-  };
-  uint32_t n_eq = 0, n_lt = 0;
-  for (uint32_t p = p0; p < p1; p++) {
-    const uint4 q = kp[p];
-    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-    const uint32_t g0 = a0 + 16u * p;
-    if (g0 >= bs && g0 + 16u <= be) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) { n_eq += __popc(eq_bits(wd[j])); n_lt += __popc(lt_bits(wd[j])); }
-    } else {
-      uint32_t vb[4];
-      valid_bits(p, vb);
-#pragma unroll
-      for (int j = 0; j < 4; j++) { n_eq += __popc(eq_bits(wd[j]) & vb[j]); n_lt += __popc(lt_bits(wd[j]) & vb[j]); }
-    }
-  }
-  // block: total of n_lt, exclusive scan (thread order) + total of n_eq
-  uint32_t my_off, n, start;
-  {
-    uint32_t inc = n_eq, lt = n_lt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t t = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += t;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) lt += __shfl_xor(lt, d, 64);
-    __syncthreads();                                  // (red[] was read above)
-    if (lane == 63) scan4[w] = inc;
-    if (lane == 0) red[4 + w] = lt;
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) if (i < w) base += scan4[i];
-    my_off = base + inc - n_eq;
-    n = (scan4[0] + scan4[1]) + (scan4[2] + scan4[3]);
-    start = bs + ((red[4] + red[5]) + (red[6] + red[7]));
-  }
-  if (ABOVE == 0 && tid == 0) ranges[tile] = make_uint2(start, start + n);
-  if (n == 0u || n <= (uint32_t)ABOVE) return;       // block-uniform
-  if (CAP < GSR_TLO_CAP && n > (uint32_t)CAP) return;  // (the second launch orders it)
+  if (n <= 1u || n <= (uint32_t)ABOVE) return;              // block-uniform (ABOVE: the lists another launch orders)
+  if (CAP < GSR_TLO_CAP && n > (uint32_t)CAP) return;
   // longest list of this frame, for the caller's choice of binning form - only lists past half the LDS capacity report
   // (same-address atomics cost ~15 ns each on this part: one per tile would be 0.12 ms at 1080p)
   if (CAP == GSR_TLO_CAP && tid == 0 && n > GSR_TLO_CAP / 2) atomicMax(&meta[4], n);
-  const bool in_lds = n <= (uint32_t)CAP;
-  // ---- pass 2 (the pieces come out of L1 / L2 now): positions of this tile's instances, in order ----
-  {
-    uint32_t k = my_off;
-    uint32_t* dst = in_lds ? mpos : free_c + start;
-    for (uint32_t p = p0; p < p1; p++) {
-      const uint4 q = kp[p];
-      const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-      const uint32_t g0 = a0 + 16u * p;
-      uint32_t vb[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
-      if (!(g0 >= bs && g0 + 16u <= be)) valid_bits(p, vb);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        uint32_t m = eq_bits(wd[j]) & vb[j];
-        while (m) {
-          const int bit = __ffs((int)m) - 1;
-          dst[k++] = g0 + 4u * j + ((uint32_t)bit >> 3) - bs;
-          m &= m - 1u;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (in_lds) {
-    // LDS path: stable LSD radix sort of the list's 32-bit depth keys (8-bit digits, passes whose digit is the same for every
-    // key are skipped - the keys of one tile usually differ in their low ~20 bits only), ranked like the global sort: each
-    // wave ranks a contiguous quarter of the list with ballots and wave-private counters.  The position in the id-ordered
-    // input rides along, so equal depths keep ascending id.  Linear in the list length (a bitonic network on the same data
-    // moved 20x the bytes through LDS and took 0.17 ms per frame at C3).
+  if (n <= (uint32_t)CAP) {
     uint32_t diff = 0, k0 = 0;
     for (uint32_t i = tid; i < n; i += 256) {
-      const uint32_t g = gid_b[bs + mpos[i]];
+      const uint32_t g = point_list[x + i];
       const uint32_t d = g != 0xFFFFFFFFu ? depth_key[g] : 0xFFFFFFFFu;   // (padding slot of k_emit_instances: last)
       skey[i] = d;
       sidx[i] = (uint16_t)i;
@@ -375,22 +257,35 @@ __global__ __launch_bounds__(256) void k_tile_gather_sort(int tiles, int bshift,
       }
       __syncthreads();
     }
-    // the list (and the emission slots) in their final order and place
-    for (uint32_t i = tid; i < n; i += 256) {
-      const uint32_t src = bs + mpos[sidx[i]];
-      point_list[start + i] = gid_b[src];
-      if (DUAL) slot_of_pos[start + i] = slot_b[src];
+    // permute the payloads in place: every source is read before anything is written
+    uint32_t gsrc[CAP / 256], ssrc[DUAL ? CAP / 256 : 1];
+#pragma unroll
+    for (int u = 0; u < CAP / 256; u++) {
+      const uint32_t i = (uint32_t)u * 256 + tid;
+      if (i < n) {
+        const uint32_t src = sidx[i];
+        gsrc[u] = point_list[x + src];
+        if (DUAL) ssrc[u] = slot_of_pos[x + src];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < CAP / 256; u++) {
+      const uint32_t i = (uint32_t)u * 256 + tid;
+      if (i < n) {
+        point_list[x + i] = gsrc[u];
+        if (DUAL) slot_of_pos[x + i] = ssrc[u];
+      }
     }
     return;
   }
   uint32_t npad = 2;
   while (npad < n) npad <<= 1;
-  // ---- a list beyond the LDS capacity: a sorting network on (free_a = depth bits, free_b = position) in global memory, over
-  // the list's own range [start, start + n) of the scratch arrays; free_c holds the instances' positions inside the bucket ----
+  // ---- a list beyond the LDS capacity: the same network on (free_a = depth bits, free_b = position) in global memory ----
   for (uint32_t i = tid; i < n; i += 256) {
-    const uint32_t g = gid_b[bs + free_c[start + i]];
-    free_a[start + i] = g != 0xFFFFFFFFu ? depth_key[g] : 0xFFFFFFFFu;
-    free_b[start + i] = i;
+    const uint32_t g = point_list[x + i];
+    free_a[x + i] = g != 0xFFFFFFFFu ? depth_key[g] : 0xFFFFFFFFu;
+    free_b[x + i] = i;
   }
   __syncthreads();
   // "normalised" bitonic network: every compare-exchange is ascending (the smaller key goes to the lower index), the first
@@ -398,11 +293,11 @@ __global__ __launch_bounds__(256) void k_tile_gather_sort(int tiles, int bshift,
   // the larger partner and therefore never move, so no padding has to exist in memory.
   auto cmpx = [&](uint32_t i, uint32_t l) __attribute__((always_inline)) {
     if (l >= n) return;
-    const unsigned long long a = ((unsigned long long)free_a[start + i] << 32) | free_b[start + i];
-    const unsigned long long b = ((unsigned long long)free_a[start + l] << 32) | free_b[start + l];
+    const unsigned long long a = ((unsigned long long)free_a[x + i] << 32) | free_b[x + i];
+    const unsigned long long b = ((unsigned long long)free_a[x + l] << 32) | free_b[x + l];
     if (a > b) {
-      free_a[start + i] = (uint32_t)(b >> 32); free_b[start + i] = (uint32_t)b;
-      free_a[start + l] = (uint32_t)(a >> 32); free_b[start + l] = (uint32_t)a;
+      free_a[x + i] = (uint32_t)(b >> 32); free_b[x + i] = (uint32_t)b;
+      free_a[x + l] = (uint32_t)(a >> 32); free_b[x + l] = (uint32_t)a;
     }
   };
   for (uint32_t k = 2; k <= npad; k <<= 1) {
@@ -420,40 +315,48 @@ __global__ __launch_bounds__(256) void k_tile_gather_sort(int tiles, int bshift,
       __syncthreads();
     }
   }
-  for (uint32_t i = tid; i < n; i += 256) {
-    const uint32_t src = bs + free_c[start + free_b[start + i]];
-    point_list[start + i] = gid_b[src];
-    if (DUAL) slot_of_pos[start + i] = slot_b[src];
+  for (uint32_t i = tid; i < n; i += 256) free_c[x + i] = point_list[x + free_b[x + i]];
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += 256) point_list[x + i] = free_c[x + i];
+  if (DUAL) {
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) free_c[x + i] = slot_of_pos[x + free_b[x + i]];
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) slot_of_pos[x + i] = free_c[x + i];
   }
 }
 
-void gsr_launch_tile_gather_sort(int tiles, bool dual, const uint32_t* bucket_hist, const uint8_t* bkey8,
-                                 const uint32_t* gid_b, const uint32_t* slot_b, const uint32_t* depth_key,
-                                 uint32_t* point_list, uint32_t* slot_of_pos, uint2* ranges, uint32_t* free_a,
-                                 uint32_t* free_b, uint32_t* free_c, uint32_t* meta, const uint32_t* n_dev, uint32_t cap,
-                                 hipStream_t st) {
-  const int bshift = gsr_bucket_shift(tiles);
-  const int nb = gsr_bucket_count(tiles);
-  const unsigned grid = 8u * (unsigned)((nb + 7) / 8) << bshift;
-#define GSR_TGS_ARGS tiles, bshift, bucket_hist, bkey8, gid_b, slot_b, depth_key, point_list, slot_of_pos, ranges, free_a, free_b, free_c, meta, n_dev, cap
-  // two launches by list length: lists up to GSR_TLO_SMALL with a quarter of the LDS (more tiles in flight per CU)
+void gsr_launch_tile_depth_sort(int tiles, bool dual, const uint2* ranges, uint32_t* point_list, uint32_t* slot_of_pos,
+                                const uint32_t* depth_key, uint32_t* free_a, uint32_t* free_b, uint32_t* free_c,
+                                uint32_t* meta, hipStream_t st) {
+#if GSR_TLO_SPLIT
   if (dual) {
-    GSR_LAUNCH("tile_gather_sort", (k_tile_gather_sort<true, GSR_TLO_SMALL, 0>), dim3(grid), dim3(256), 0, st, GSR_TGS_ARGS);
-    GSR_LAUNCH("tile_gather_sort_long", (k_tile_gather_sort<true, GSR_TLO_CAP, GSR_TLO_SMALL>), dim3(grid), dim3(256), 0, st, GSR_TGS_ARGS);
+    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<true, GSR_TLO_SMALL, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
+               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+    GSR_LAUNCH("tile_depth_sort_long", (k_tile_depth_sort<true, GSR_TLO_CAP, GSR_TLO_SMALL>), dim3(tiles), dim3(256), 0, st, ranges,
+               point_list, slot_of_pos, depth_key, free_a, free_b, free_c, meta);
   } else {
-    GSR_LAUNCH("tile_gather_sort", (k_tile_gather_sort<false, GSR_TLO_SMALL, 0>), dim3(grid), dim3(256), 0, st, GSR_TGS_ARGS);
-    GSR_LAUNCH("tile_gather_sort_long", (k_tile_gather_sort<false, GSR_TLO_CAP, GSR_TLO_SMALL>), dim3(grid), dim3(256), 0, st, GSR_TGS_ARGS);
+    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<false, GSR_TLO_SMALL, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
+               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+    GSR_LAUNCH("tile_depth_sort_long", (k_tile_depth_sort<false, GSR_TLO_CAP, GSR_TLO_SMALL>), dim3(tiles), dim3(256), 0, st, ranges,
+               point_list, slot_of_pos, depth_key, free_a, free_b, free_c, meta);
   }
-#undef GSR_TGS_ARGS
+#else
+  if (dual)
+    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<true, GSR_TLO_CAP, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
+               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+  else
+    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<false, GSR_TLO_CAP, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
+               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+#endif
 }
 
 void gsr_launch_emit(int P, int grid_x, int tiles, const char* geom, const GsrGeomLayout& GL, char* bin,
-                     const GsrBinLayout& BL, uint32_t cap, bool index_order, uint32_t* key_dst, uint32_t* gid_dst,
-                     hipStream_t st) {
+                     const GsrBinLayout& BL, uint32_t cap, bool index_order, hipStream_t st) {
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
              index_order ? (const uint32_t*)nullptr : (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
              (const uint32_t*)(geom + GL.tiles_touched),
-             (const float4*)(geom + GL.bin_rec), key_dst, gid_dst,
+             (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
              (uint32_t*)(geom + GL.slot_start), tiles, (uint2*)(bin + BL.ranges), cap, (uint32_t*)(bin + BL.radix_tmp));
 }
 

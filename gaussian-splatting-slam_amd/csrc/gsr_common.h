@@ -46,17 +46,12 @@ struct GsrGeomLayout {
   size_t total;
 };
 
-// Two sets of (tile key, emission slot, Gaussian id) arrays: the tile sort ping-pongs between them.  Whatever the form of the
-// binning stage and the number of passes, the FINAL per-tile lists end up in set F: gid_f = Gaussian ids sorted by (tile, depth,
-// id), val_f = the emission slot of every list position (where the backward stores that instance's gradient record).  The
-// instance emission therefore starts in X or F by the parity of the passes that follow (api.hip).
 struct GsrBinLayout {
-  size_t key_x, val_x, gid_x;   // u32[R] each
-  size_t key_f, val_f, gid_f;   // u32[R] each; val_f / gid_f: final slot_of_pos / point_list
-  size_t bkey8;                 // u8[R]   bucket form: tile id inside its bucket, in bucket order
-  size_t tmp_a, tmp_b;          // u32[R]  bucket form: scratch of the in-memory path for lists beyond the LDS capacity
-  size_t ranges;                // uint2[tiles]
-  size_t bucket_hist;           // u32[GSR_BUCKET_MAX]  bucket form: instances per bucket
+  size_t key_a, key_b;   // u32[R] tile ids (ping-pong)
+  size_t val_a, val_b;   // u32[R] emission slots (ping-pong); the sorted one (slot of each position) is kept for the backward
+  size_t gauss_of_slot;  // u32[R] Gaussian id of each emission slot; second payload of the tile sort, ping-pongs with
+  size_t point_list;     // u32[R] -> Gaussian ids sorted by (tile, depth, id) end up in ONE of the two (pass parity)
+  size_t ranges;         // uint2[tiles]
   size_t scan_tmp;
   size_t radix_tmp;
   size_t total;
@@ -137,46 +132,17 @@ static inline GsrGeomLayout gsr_geom_layout(size_t P) {
   return L;
 }
 
-// Bucket form of the binning stage (binning.hip): a bucket = 2^shift consecutive tile ids.  Instances are sorted by BUCKET only
-// (one radix pass up to 256 buckets, two up to 1024) and every tile then picks its own entries out of its bucket.  Tiles per
-// bucket: 32, more only when that would give more than 1024 buckets; keys inside a bucket are one byte and the per-tile scan
-// compares them 4 at a time with 7-bit arithmetic, so at most 128 tiles per bucket: 131072 tiles (a 5792 x 5792 image) is the
-// largest the form takes (api.hip falls back to the global form beyond).
-#define GSR_BUCKET_MAX 1024
-#define GSR_BUCKET_MAX_SHIFT 7
-static inline __host__ __device__ int gsr_bucket_shift(int tiles) {
-  int s = 5;
-  while (s < GSR_BUCKET_MAX_SHIFT && ((tiles + (1 << s) - 1) >> s) > GSR_BUCKET_MAX) s++;
-  return s;
-}
-static inline __host__ __device__ bool gsr_bucket_form_ok(int tiles) {
-  return ((tiles + (1 << GSR_BUCKET_MAX_SHIFT) - 1) >> GSR_BUCKET_MAX_SHIFT) <= GSR_BUCKET_MAX;
-}
-static inline __host__ __device__ int gsr_bucket_count(int tiles) {
-  const int s = gsr_bucket_shift(tiles);
-  return (tiles + (1 << s) - 1) >> s;
-}
-static inline __host__ __device__ int gsr_bits_for(int n) {   // bits needed for values 0 .. n-1 (at least 1)
-  int b = 1;
-  while ((1 << b) < n) b++;
-  return b;
-}
-
 static inline GsrBinLayout gsr_bin_layout(size_t R, size_t tiles) {
   GsrBinLayout L;
   size_t o = 0;
   if (R == 0) R = 1;
-  L.key_x = o;         o += gsr_align(R * 4);
-  L.val_x = o;         o += gsr_align(R * 4);
-  L.gid_x = o;         o += gsr_align(R * 4);
-  L.key_f = o;         o += gsr_align(R * 4);
-  L.val_f = o;         o += gsr_align(R * 4);
-  L.gid_f = o;         o += gsr_align(R * 4);
-  L.bkey8 = o;         o += gsr_align(R + 64);      // (+64: the per-tile scan reads whole 16-B pieces)
-  L.tmp_a = o;         o += gsr_align(R * 4);
-  L.tmp_b = o;         o += gsr_align(R * 4);
+  L.key_a = o;         o += gsr_align(R * 4);
+  L.key_b = o;         o += gsr_align(R * 4);
+  L.val_a = o;         o += gsr_align(R * 4);
+  L.val_b = o;         o += gsr_align(R * 4);
+  L.gauss_of_slot = o; o += gsr_align(R * 4);
+  L.point_list = o;    o += gsr_align(R * 4);
   L.ranges = o;        o += gsr_align(tiles * 8);
-  L.bucket_hist = o;   o += gsr_align(GSR_BUCKET_MAX * 4);
   L.scan_tmp = o;      o += gsr_align(gsr_scan_tmp_elems(R) * 4);
   L.radix_tmp = o;     o += gsr_align(gsr_radix_tmp_elems(R) * 4);
   L.total = o;
@@ -237,11 +203,7 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 // caller that does not know the count on the host: gsr_forward_async).
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
                          int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0 = nullptr, uint32_t* w1 = nullptr,
-                         const uint32_t* n_dev = nullptr, bool head_zeroed = false, int shift0 = 0,
-                         uint8_t* keys8_out = nullptr, uint32_t* bucket_hist = nullptr);
-// shift0: the sort runs on key bits [shift0, shift0 + bits).  keys8_out (bucket form of the binning stage): the LAST pass writes
-// the low `shift0` bits of every key as ONE byte there instead of the 32-bit key; bucket_hist then receives the count of every
-// value of the sorted bit field (2^bits <= GSR_BUCKET_MAX counters, zeroed by the sort).
+                         const uint32_t* n_dev = nullptr, bool head_zeroed = false);
 // head_zeroed: the caller guarantees that the first GSR_RADIX_HEAD_WORDS words of `tmp` are zero when the sort's first kernel
 // starts (an earlier kernel of the same stream cleared them); otherwise the sort enqueues a memset of its own.
 

@@ -159,21 +159,14 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 #define GSR_LB_WINDOW 8
 #endif
 
-// shift0: the sorted field is key bits [shift0, shift0 + bits).  BUCKETS (bucket form of the binning stage with more than one
-// pass): additionally the histogram of the WHOLE field (<= GSR_BUCKET_MAX values) into bucket_hist - with one pass it is the
-// pass's own digit histogram and the caller points bucket_hist at it.
-template <bool BUCKETS>
 __global__ __launch_bounds__(256) void k_radix_hist_all(const uint32_t* __restrict__ keys, size_t n_max,
-                                                        const uint32_t* __restrict__ n_dev, int bits, int shift0,
+                                                        const uint32_t* __restrict__ n_dev, int bits,
                                                         uint32_t* __restrict__ hist, uint32_t* __restrict__ lookback,
-                                                        size_t lookback_words, uint32_t* __restrict__ bucket_hist) {
+                                                        size_t lookback_words) {
   __shared__ uint32_t lh[GSR_RADIX_MAX_PASSES * GSR_RADIX_SIZE];
-  __shared__ uint32_t lb[BUCKETS ? GSR_BUCKET_MAX : 1];
   const size_t n = gsr_eff_n(n_dev, (uint32_t)n_max);
   const int passes = gsr_radix_passes(bits);
   for (int i = threadIdx.x; i < passes * GSR_RADIX_SIZE; i += 256) lh[i] = 0;
-  if (BUCKETS)
-    for (int i = threadIdx.x; i < GSR_BUCKET_MAX; i += 256) lb[i] = 0;
   __syncthreads();
   // the look-back words of every pass start at "nothing published" (keys_in is 256-B aligned, so is the table)
   {
@@ -182,7 +175,6 @@ __global__ __launch_bounds__(256) void k_radix_hist_all(const uint32_t* __restri
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   auto count = [&](uint32_t k) __attribute__((always_inline)) {
-    k >>= shift0;
 #pragma unroll
     for (int p = 0; p < GSR_RADIX_MAX_PASSES; p++) {
       if (p < passes) {
@@ -190,7 +182,6 @@ __global__ __launch_bounds__(256) void k_radix_hist_all(const uint32_t* __restri
         atomicAdd(&lh[p * GSR_RADIX_SIZE + d], 1u);
       }
     }
-    if (BUCKETS) atomicAdd(&lb[k & ((1u << bits) - 1u)], 1u);
   };
   const size_t n4 = n >> 2;
   const uint4* k4 = reinterpret_cast<const uint4*>(keys);
@@ -215,11 +206,6 @@ __global__ __launch_bounds__(256) void k_radix_hist_all(const uint32_t* __restri
     const uint32_t c = lh[i];
     if (c) atomicAdd(&hist[i], c);
   }
-  if (BUCKETS)
-    for (int i = threadIdx.x; i < (1 << bits); i += 256) {
-      const uint32_t c = lb[i];
-      if (c) atomicAdd(&bucket_hist[i], c);
-    }
 }
 
 // One pass.  Each workgroup owns one chunk of 256 * SUBTILES keys; wave w owns the contiguous quarter of it, SUBTILES
@@ -242,8 +228,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ hist /* this pass: [256] */,
                                                     uint32_t* __restrict__ ticket, uint32_t* lookback /* [chunks][256] */,
                                                     size_t n_max, const uint32_t* __restrict__ n_dev, int shift,
-                                                    uint32_t mask, uint8_t* __restrict__ keys8_out, uint32_t low_mask) {
-  // keys8_out (last pass of the bucket form): the key leaves as ONE byte, its bits below the sorted field (key & low_mask)
+                                                    uint32_t mask) {
   __shared__ uint32_t wave_run[4][GSR_RADIX_SIZE];  // phase 1: keys of (wave, digit) seen so far; phase 2: the wave's base
   __shared__ uint32_t lstart[GSR_RADIX_SIZE];       // first local (sorted) position of each digit
   __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
@@ -258,8 +243,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
     if (__syncthreads_or(hist[tid] == (uint32_t)n0 && n0 != 0)) {
       const size_t b0 = (size_t)blockIdx.x * (256 * SUBTILES);
       for (uint32_t i = tid; i < (uint32_t)(256 * SUBTILES) && b0 + i < n0; i += 256) {
-        if (keys8_out) keys8_out[b0 + i] = (uint8_t)(keys_in[b0 + i] & low_mask);
-        else keys_out[b0 + i] = keys_in[b0 + i];
+        keys_out[b0 + i] = keys_in[b0 + i];
         vals_out[b0 + i] = vals_in ? vals_in[b0 + i] : (uint32_t)(b0 + i);
         if (DUAL) vals2_out[b0 + i] = vals2_in[b0 + i];
       }
@@ -400,8 +384,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
       const uint32_t kk = lbuf[i];
       const uint32_t d = (kk >> shift) & mask;
       gpos[k] = gbase[d] + (i - lstart[d]);
-      if (keys8_out) keys8_out[gpos[k]] = (uint8_t)(kk & low_mask);
-      else keys_out[gpos[k]] = kk;
+      keys_out[gpos[k]] = kk;
     }
   }
   __syncthreads();
@@ -431,7 +414,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
 
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
                          int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0, uint32_t* w1, const uint32_t* n_dev,
-                         bool head_zeroed, int shift0, uint8_t* keys8_out, uint32_t* bucket_hist) {
+                         bool head_zeroed) {
   if (n == 0 || bits <= 0) return 0;
   const uint32_t nblk = (uint32_t)gsr_radix_blocks(n);
   const int subtiles = gsr_radix_subtiles(n);
@@ -446,30 +429,22 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
   // one workgroup per CU: every workgroup ends with one global add per non-zero counter, and adds to ONE address serialise
   // (~15 ns each): 128 / 256 / 512 / 1024 workgroups -> 22 / 17 / 21 / 29 us at 4.4 M keys
   const unsigned hgrid = nblk < 256u ? nblk : 256u;
-  const bool want_buckets = bucket_hist != nullptr && passes > 1;
-  if (want_buckets) {
-    (void)hipMemsetAsync(bucket_hist, 0, (size_t)GSR_BUCKET_MAX * 4, st);
-    GSR_LAUNCH("radix_hist", k_radix_hist_all<true>, dim3(hgrid), dim3(256), 0, st, (const uint32_t*)k0, n, n_dev, bits, shift0,
-               hist, lookback, lb_words, bucket_hist);
-  } else {
-    GSR_LAUNCH("radix_hist", k_radix_hist_all<false>, dim3(hgrid), dim3(256), 0, st, (const uint32_t*)k0, n, n_dev, bits, shift0,
-               hist, lookback, lb_words, (uint32_t*)nullptr);
-  }
+  GSR_LAUNCH("radix_hist", k_radix_hist_all, dim3(hgrid), dim3(256), 0, st, (const uint32_t*)k0, n, n_dev, bits, hist,
+             lookback, lb_words);
   int cur = 0;
   for (int pass = 0; pass < passes; pass++) {
-    const int shift = shift0 + gsr_radix_shift(bits, pass);
+    const int shift = gsr_radix_shift(bits, pass);
     const uint32_t mask = (1u << gsr_radix_width(bits, pass)) - 1u;
     uint32_t* ki = cur ? k1 : k0;
     uint32_t* vi = cur ? v1 : v0;
     uint32_t* ko = cur ? k0 : k1;
     uint32_t* vo = cur ? v0 : v1;
     const uint32_t* vin = (pass == 0 && vals_iota) ? nullptr : vi;
-    uint8_t* k8 = (pass == passes - 1) ? keys8_out : nullptr;
 #define GSR_PASS(D, S)                                                                                                 \
   GSR_LAUNCH("radix_pass", (k_radix_pass<D, S>), dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,               \
              (const uint32_t*)(D ? (cur ? w1 : w0) : nullptr), ko, vo, (uint32_t*)(D ? (cur ? w0 : w1) : nullptr),      \
              (const uint32_t*)(hist + pass * GSR_RADIX_SIZE), tickets + pass,                                          \
-             lookback + (size_t)pass * nblk * GSR_RADIX_SIZE, n, n_dev, shift, mask, k8, (1u << shift0) - 1u)
+             lookback + (size_t)pass * nblk * GSR_RADIX_SIZE, n, n_dev, shift, mask)
     if (dual) {
       if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_PASS(true, GSR_RADIX_SUBTILES_SMALL);
       else GSR_PASS(true, GSR_RADIX_SUBTILES);
