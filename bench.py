@@ -270,9 +270,10 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views per rank per optimizer step (gradient accumulation; default 1 = the reference's batch-1 step). "
                          "Amortises the N>1 gradient exchange and Adam over k views; value still counts view-iterations")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "visible_rows", "sharded"],
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "visible_rows", "sharded", "sh_rank1"],
                     help="N>1 gradient exchange: one all-reduce per leaf tensor (north-star schedule); the same restricted to the "
-                         "rows some rank saw; or reduce-scatter -> Adam on a 1/N row shard -> all-gather (DESIGN.md 5)")
+                         "rows some rank saw; reduce-scatter -> Adam on a 1/N row shard -> all-gather; or sh_rank1: geometry "
+                         "all-reduced, the SH gradients rebuilt from an all-gather of dL/df_dc (DESIGN.md 5)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: exchange all gradients on the main stream (default overlaps the SH exchange + Adam with the next "
                          "step's geometry stages; same results, DESIGN.md 5)")
@@ -322,7 +323,7 @@ def main():
         sys.exit(subprocess.call(cmd))
 
     torch.set_num_threads(host_threads())
-    from scene_utils import init_from_env, Trainer
+    from scene_utils import init_from_env, Trainer, exchange_bytes_per_gaussian
     # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1 rehearse the N>1 path with several ranks on ONE card (no RCCL between them)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     rank, world, local = init_from_env(backend)
@@ -432,6 +433,8 @@ def main():
                    "sh_degree": cfg["deg"], "width": W, "height": H, "views": len(cams),
                    "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}",
                    "views_per_rank_per_step": k, "overlap_comm": bool(trainer.overlap_comm), "exchange": trainer.exchange,
+                   "exchange_bytes_per_gaussian_received": round(exchange_bytes_per_gaussian(trainer.exchange, world, M), 1)
+                                                            if world > 1 else 0,
                    "loss": "L1 + 0.2 DSSIM (" + ("HIP fused SSIM" if args.loss == "hip" else "torch conv2d SSIM") + ")",
                    "optimizer": {"hip": "Adam, one-launch HIP kernel (torch.optim.Adam semantics)",
                                  "hip_fused": "Adam (torch.optim.Adam semantics) folded into the rasterizer backward",

@@ -102,6 +102,69 @@ class GradBucket:
         return int(idx.numel())
 
 
+def rank1_sh_exchange(xyz, f_dc, f_rest, cam_center, sh_degree: int, world: int, group=None):
+    """Exchange of the two SH gradient tensors for ONE view per rank per step (`exchange="sh_rank1"`).
+
+    A view's SH gradient is rank one per Gaussian: dL/dsh[k][c] = basis_k(dir) * dL/drgb_c (SURVEY.md A.7 iv), and band 0's
+    basis is the constant C0, so this rank's `f_dc.grad` (= C0 * dL/drgb, zero where the colour was clamped) holds all the
+    information `f_rest.grad` [P, 15, 3] is made of.  The ranks all-gather f_dc.grad and their camera centre - 12 B per Gaussian
+    and rank instead of all-reducing 192 B - and every rank rebuilds the MEAN of both gradients locally, summing the ranks in
+    order (csrc/exchange.hip on the HIP device; the same arithmetic in torch ops on the CPU for the gloo tests): identical bits
+    on every rank; against the all-reduce schedule the values agree to fp32 rounding of the individual products
+    ((b / C0) (C0 g) instead of b g, and a fixed instead of the collective's summation order).
+    `xyz`: the positions the forwards saw (call before the optimizer moves them).  Leaves the means in f_dc.grad / f_rest.grad."""
+    P = int(xyz.shape[0])
+    krest = int(f_rest.shape[1]) if f_rest.numel() else 0
+    g = f_dc.grad if f_dc.grad is not None else torch.zeros_like(f_dc)
+    mine = torch.cat((g.reshape(P, 3), cam_center.reshape(1, 3).to(g)), dim=0).contiguous()        # [P + 1, 3]
+    gathered = torch.empty(world * (P + 1), 3, dtype=g.dtype, device=g.device)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    out_dc = torch.empty_like(f_dc)
+    out_rest = torch.empty_like(f_rest)
+    if g.is_cuda:
+        import ctypes as C
+        from diff_gaussian_rasterization import _C
+        with _C.on_device(g.device):
+            _C.check(_C.lib().gsr_sh_rank1_expand(P, world, int(sh_degree), krest, _C.ptr(xyz.detach().contiguous()),
+                                                  _C.ptr(gathered), C.c_float(1.0 / world), _C.ptr(out_dc),
+                                                  _C.ptr(out_rest) if krest else None, _C._stream()))
+    else:
+        from .sh import sh_basis, C0
+        gathered = gathered.view(world, P + 1, 3)
+        acc_dc = torch.zeros(P, 3, dtype=g.dtype)
+        acc = torch.zeros(P, krest, 3, dtype=g.dtype)
+        K = (sh_degree + 1) ** 2
+        for r in range(world):
+            gr, cam = gathered[r, :P], gathered[r, P]
+            acc_dc += gr
+            if krest and K > 1:
+                d = xyz.detach() - cam
+                d = d / d.norm(dim=1, keepdim=True)
+                w = sh_basis(sh_degree, d)[:, 1:K] * (1.0 / C0)                                  # [P, K - 1]
+                acc[:, :K - 1] += w[:, :, None] * gr[:, None, :]
+        out_dc.copy_((acc_dc * (1.0 / world)).view_as(out_dc))
+        out_rest.copy_(acc * (1.0 / world))
+    f_dc.grad = out_dc
+    f_rest.grad = out_rest
+
+
+def exchange_bytes_per_gaussian(exchange: str, world: int, sh_coeffs: int = 16, visible_fraction: float = 1.0):
+    """Bytes a rank RECEIVES per Gaussian and step over the links (ring / direct algorithms: an all-reduce of b bytes moves
+    2 (N-1)/N b, reduce-scatter and all-gather (N-1)/N b each, an all-gather of b bytes per rank (N-1) b) - the table of DESIGN.md 5."""
+    n = world
+    row = 4 * (11 + 3 * sh_coeffs)                     # 59 floats at SH degree 3
+    f = (n - 1) / n
+    if exchange == "allreduce":
+        return 2 * f * row
+    if exchange == "sharded":
+        return f * row + f * row
+    if exchange == "visible_rows":
+        return 2 * f * (1 + row * visible_fraction)    # + the 1-byte mask
+    if exchange == "sh_rank1":
+        return 2 * f * 4 * 11 + (n - 1) * 12           # geometry all-reduced, dL/df_dc all-gathered
+    raise ValueError(exchange)
+
+
 class ShardedStep:
     """reduce-scatter -> optimizer on a 1/N ROW shard -> all-gather of the parameters (the exchange DESIGN.md 5 sizes for xGMI).
 

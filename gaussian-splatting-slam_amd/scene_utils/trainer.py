@@ -6,7 +6,7 @@ from __future__ import annotations
 import torch
 
 from .losses import training_loss_fused
-from .parallel import GradBucket, reduce_densification_stats
+from .parallel import GradBucket, reduce_densification_stats, rank1_sh_exchange
 
 
 class _LazyVisibility:
@@ -51,7 +51,9 @@ class Trainer:
         # N > 1 gradient exchange: "allreduce" (one all-reduce per leaf, every rank runs the whole update),
         # "visible_rows" (the same, restricted to the rows some rank saw), "sharded" (reduce-scatter -> Adam on a 1/N row shard
         # -> all-gather of the parameters; dense optimizers, no densification yet: the moments live per shard)
-        if exchange not in ("allreduce", "visible_rows", "sharded"):
+        # "sh_rank1" (one view per rank per step): the 11 geometry floats are all-reduced, the 48 SH floats are rebuilt from an
+        # all-gather of dL/df_dc + camera centres (parallel.rank1_sh_exchange): 161 instead of 413 B per Gaussian at N = 8
+        if exchange not in ("allreduce", "visible_rows", "sharded", "sh_rank1"):
             raise ValueError(exchange)
         self.exchange = exchange if world > 1 else "allreduce"
         self.sharded = None
@@ -73,7 +75,7 @@ class Trainer:
         # HIP optimizers (they step parameter groups separately) and dc / rest passed unconcatenated (separate_sh), because a
         # torch.cat of the SH tensors would read them on the main stream while their update is still in flight.
         can_overlap = optimizer in ("hip", "hip_sparse") and separate_sh and model.get_xyz.is_cuda and \
-            self.exchange == "allreduce"
+            self.exchange in ("allreduce", "sh_rank1")
         # default: on for N > 1.  On one GPU it can be requested, but it buys nothing (measured 2.22 vs 2.21 ms/step at C3: the
         # Adam kernel fills the machine, the small geometry kernels just queue behind it); what it hides is COMMUNICATION.
         self.overlap_comm = (can_overlap and world > 1) if overlap_comm is None else (bool(overlap_comm) and can_overlap)
@@ -171,8 +173,10 @@ class Trainer:
             v8 = vis.get().to(torch.uint8)
             dist.all_reduce(v8, op=dist.ReduceOp.MAX)
             vis = _LazyVisibility(None, v8.bool())
+        # the rank-one form of the SH exchange holds for ONE view's gradient (one direction per Gaussian)
+        rank1_cam = self.cameras[views[0]].camera_center if (self.exchange == "sh_rank1" and len(views) == 1) else None
         if self.overlap_comm and not self._densify_due():
-            self._exchange_and_step_overlapped(vis.get() if self.optimizer_kind == "hip_sparse" else None, radii)
+            self._exchange_and_step_overlapped(vis.get() if self.optimizer_kind == "hip_sparse" else None, radii, rank1_cam)
             return self.last
         if self.sharded is not None:
             if self.densify is not None:
@@ -180,7 +184,11 @@ class Trainer:
             self.sharded.step()
             return self.last
         with torch.no_grad():
-            if self.bucket is not None:
+            if self.bucket is not None and rank1_cam is not None:
+                m = self.model
+                self.bucket.all_reduce_mean(self.world, params=[m._xyz, m._opacity, m._scaling, m._rotation])
+                rank1_sh_exchange(m._xyz, m._features_dc, m._features_rest, rank1_cam, m.active_sh_degree, self.world)
+            elif self.bucket is not None:
                 self.bucket.all_reduce_mean(self.world, visible=vis.get() if self.exchange == "visible_rows" else None)
             if self.densify is not None:
                 # the reference densifies between backward and the optimizer step (train.py:155-168 before :170): the
@@ -236,7 +244,7 @@ class Trainer:
         return m is not None and int(self.model.get_xyz.shape[0]) >= m
 
     @torch.no_grad()
-    def _exchange_and_step_overlapped(self, vis, radii):
+    def _exchange_and_step_overlapped(self, vis, radii, rank1_cam=None):
         """Synchronous data parallelism, same result as the plain path, different schedule: the SH gradients (f_dc, f_rest:
         48 of the 59 floats per Gaussian) are all-reduced and applied on a side stream; the main stream exchanges and applies
         the geometry gradients (11 floats) and goes straight on to the next step, whose rasterizer runs projection, depth
@@ -257,7 +265,15 @@ class Trainer:
                     p.grad.record_stream(side)
             if vis is not None:
                 vis.record_stream(side)
-            if self.bucket is not None:
+            if self.bucket is not None and rank1_cam is not None:
+                # the SH gradients are rebuilt from the ranks' dL/df_dc and the positions the forwards SAW: the main stream's
+                # geometry update must not overtake that read, so the side stream takes a copy first (12 B per Gaussian)
+                xyz_seen = m._xyz.detach().clone()
+                snap = torch.cuda.Event()
+                snap.record(side)
+                main.wait_event(snap)
+                rank1_sh_exchange(xyz_seen, m._features_dc, m._features_rest, rank1_cam, m.active_sh_degree, self.world)
+            elif self.bucket is not None:
                 self.bucket.all_reduce_mean(self.world, params=sh)
             if self.optimizer_kind == "hip_sparse":
                 self.optimizer.step(vis, radii.shape[0], only=sh_names)

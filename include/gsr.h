@@ -337,6 +337,15 @@ int gsr_gaussian_activations_backward(int32_t P, const float* raw_rotation, cons
                                       float* dL_draw_scaling, float* dL_draw_rotation, float* dL_draw_opacity,
                                       void* stream);
 
+/* View-sharded data parallelism (the reference itself is single-GPU): with ONE view per rank per step the SH
+ * gradient of a rank is rank one per Gaussian, dL/dsh[k][c] = basis_k(dir) * dL/drgb_c, and dL/df_dc = C0 * dL/drgb carries it
+ * whole.  The ranks all-gather `gathered`[n_ranks][P + 1][3]: rows 0..P-1 = that rank's dL/df_dc, row P = its camera centre
+ * (12 B per Gaussian and rank instead of 192 B all-reduced), and this call rebuilds the MEAN gradients of f_dc [P, 1, 3] and
+ * f_rest [P, sh_coeffs_rest, 3] (scale = 1 / n_ranks), summing the ranks in order: identical bits on every rank.  `means3D` are
+ * the positions the forwards saw.  Coefficients beyond the active degree get zeros. */
+int gsr_sh_rank1_expand(int32_t P, int32_t n_ranks, int32_t sh_degree, int32_t sh_coeffs_rest, const float* means3D,
+                        const float* gathered, float scale, float* dL_ddc_mean, float* dL_dsh_rest_mean, void* stream);
+
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline block).  A measurement aid, process-
  * global and meant for ONE host thread driving the library at a time: enabling it while several host threads launch
  * concurrently attributes times correctly per thread (the open event pair is thread-local) but adds a lock to every launch. */

@@ -15,7 +15,7 @@ from scene_utils import init_from_env, shard_views, Trainer, GaussianModel, make
 from gaussian_renderer import render, PipelineParams  # noqa: E402
 
 
-def run(overlap, optimizer, rank, world, steps=6):
+def run(overlap, optimizer, rank, world, steps=6, exchange="allreduce"):
     dev = "cuda:0"
     raw = make_gaussians(3000, 2, seed=12, scale_factor=0.8)
     cams = fibonacci_cameras(4, 128, 80, seed=13, device=dev)
@@ -26,8 +26,8 @@ def run(overlap, optimizer, rank, world, steps=6):
         gts = {i: render(c, teacher, pipe, bg)["render"].clone() for i, c in enumerate(cams)}
     model = GaussianModel.from_raw(raw.to(dev))
     tr = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=optimizer, separate_sh=True,
-                 overlap_comm=overlap)
-    assert tr.overlap_comm == overlap
+                 overlap_comm=overlap, exchange=exchange)
+    assert tr.overlap_comm == overlap and tr.exchange == exchange
     tr.enable_densification(extent=4.4, from_iter=2, until_iter=100, interval=4, opacity_reset_interval=50, grad_threshold=2e-5)
     mine = shard_views(len(cams), rank, world)
     for it in range(steps):
@@ -50,6 +50,17 @@ def main():
             other = t.clone()
             dist.broadcast(other, src=0)
             assert torch.equal(other, t), f"ranks diverged ({optimizer})"
+    # exchange="sh_rank1" (SH gradients rebuilt from the all-gathered dL/df_dc): the overlapped schedule is bit-identical to the
+    # plain one, both ranks agree bit for bit, and the parameters match the all-reduce schedule's to fp32 rounding
+    ref = run(False, "hip", rank, world)
+    plain = run(False, "hip", rank, world, exchange="sh_rank1")
+    over = run(True, "hip", rank, world, exchange="sh_rank1")
+    for a, b, c in zip(plain, over, ref):
+        assert a.shape == b.shape and torch.equal(a, b), "overlapped sh_rank1 schedule changed the result"
+        assert a.shape == c.shape and torch.allclose(a, c, atol=1e-6, rtol=1e-4), float((a - c).abs().max())
+        other = b.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(other, b), "ranks diverged (sh_rank1)"
     if rank == 0:
         print("DP_OVERLAP_OK")
     dist.barrier()

@@ -135,6 +135,127 @@ def test_sharded_and_visible_row_exchanges_equal_the_all_reduce_schedule(tmp_pat
         assert outs["sharded"][0]["moment_bytes"] == full // 2
 
 
+@pytest.mark.timeout(900)
+def test_rank1_sh_exchange_equals_the_all_reduce_schedule_to_rounding(tmp_path):
+    """exchange="sh_rank1": geometry gradients all-reduced, the SH gradients rebuilt on every rank from an all-gather of
+    dL/df_dc + camera centres (rank one per Gaussian and view).  Two optimizer steps on two ranks: both ranks bit-identical
+    (the rebuild sums the ranks in order), and equal to the all-reduce schedule up to fp32 rounding of the individual products -
+    tolerance: |delta| <= 1e-7 + 1e-5 |p| on every parameter after the two Adam steps (measured: ~1e-9)."""
+    outs = {}
+    for k, ex in enumerate(("allreduce", "sh_rank1")):
+        d = tmp_path / ex
+        d.mkdir()
+        port = 35000 + (os.getpid() % 2000) + 7 * k
+        mp.spawn(_worker, args=(2, port, str(d), ex, 2), nprocs=2, join=True)
+        outs[ex] = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(2)]
+    for ex, (a, b) in outs.items():
+        for pa, pb in zip(a["params"], b["params"]):
+            assert torch.equal(pa, pb), ex
+    moved = False
+    for pa, pb in zip(outs["allreduce"][0]["params"], outs["sh_rank1"][0]["params"]):
+        assert torch.allclose(pa, pb, atol=1e-7, rtol=1e-5), float((pa - pb).abs().max())
+        moved |= bool((pa != pb).any())
+    # the SH tensors did go through the rebuilt gradients (f_rest is parameter 2)
+    raw, _, _ = _scene()
+    assert not torch.equal(outs["sh_rank1"][0]["params"][2], raw.features_rest)
+
+
+def test_exchange_bytes_table():
+    from scene_utils import exchange_bytes_per_gaussian as b
+    assert b("allreduce", 8) == pytest.approx(2 * 7 / 8 * 236)
+    assert b("sharded", 8) == pytest.approx(b("allreduce", 8))
+    assert b("sh_rank1", 8) == pytest.approx(2 * 7 / 8 * 44 + 7 * 12)
+    assert b("sh_rank1", 8) < 0.4 * b("allreduce", 8)
+    assert b("visible_rows", 8, visible_fraction=0.25) < 0.3 * b("allreduce", 8)
+
+
+def test_sharded_step_rccl_branches_with_an_in_process_group(monkeypatch):
+    """ShardedStep's RCCL-only branches (reduce_scatter_tensor with AVG, the in-place all_gather_into_tensor whose input is a
+    slice of its own output, the AVG all-reduce of the left-over rows) never run under gloo.  Here two threads play the two
+    ranks over an in-process stand-in for the collectives that reports itself as "nccl", 121 rows (60-row shards + one
+    left-over row), three steps: both ranks must end with the parameters of a single-process Adam on the mean gradients."""
+    import threading
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from scene_utils import GaussianModel, ShardedStep, make_gaussians
+    world = 2
+    tl = threading.local()
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+
+    class Work:
+        def wait(self):
+            return True
+
+    def everyone(t):
+        slots[tl.rank] = t.detach().clone()          # (clone: the in-place gather's input aliases its output)
+        barrier.wait()
+        vals = list(slots)
+        barrier.wait()
+        return vals
+
+    def reduce_scatter_tensor(out, inp, op=None, group=None, async_op=False):
+        assert op == dist.ReduceOp.AVG
+        vals = everyone(inp)
+        c = out.shape[0]
+        out.copy_(sum(v[tl.rank * c:(tl.rank + 1) * c] for v in vals) / world)
+        return Work()
+
+    def all_reduce(t, op=None, group=None, async_op=False):
+        assert op == dist.ReduceOp.AVG
+        vals = everyone(t)
+        t.copy_(sum(vals) / world)
+        return Work()
+
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
+        vals = everyone(inp)
+        out.copy_(torch.cat(vals, dim=0))
+        return Work()
+
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(dist, "reduce_scatter_tensor", reduce_scatter_tensor)
+    monkeypatch.setattr(dist, "all_reduce", all_reduce)
+    monkeypatch.setattr(dist, "all_gather_into_tensor", all_gather_into_tensor)
+    P, steps = 121, 3
+    results, errors = [None] * world, []
+
+    def grads_of(it, rank, model):
+        gen = torch.Generator().manual_seed(1000 * it + rank)
+        return [torch.randn(p.shape, generator=gen) for p in model.parameters()]
+
+    def run(rank):
+        try:
+            tl.rank = rank
+            model = GaussianModel.from_raw(make_gaussians(P, 1, seed=5))
+            st = ShardedStep(model, lambda groups: torch.optim.Adam(groups, lr=0.0, eps=1e-15), world, rank)
+            for it in range(steps):
+                for p, g in zip(model.parameters(), grads_of(it, rank, model)):
+                    p.grad = g
+                st.step()
+            results[rank] = [p.detach().clone() for p in model.parameters()]
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    model = GaussianModel.from_raw(make_gaussians(P, 1, seed=5))
+    opt = torch.optim.Adam(model.param_groups(), lr=0.0, eps=1e-15)
+    for it in range(steps):
+        gs = [grads_of(it, r, model) for r in range(world)]
+        for i, p in enumerate(model.parameters()):
+            p.grad = sum(g[i] for g in gs) / world
+        opt.step()
+    for a, b, ref in zip(results[0], results[1], model.parameters()):
+        assert torch.equal(a, b)
+        assert torch.equal(a, ref.detach())
+
+
 def test_sharded_step_handles_rows_not_divisible_by_world(tmp_path):
     """P = 121 on 2 ranks: 60-row shards plus one left-over row that both ranks update from the all-reduced gradient."""
     d = tmp_path / "odd"

@@ -19,7 +19,7 @@ def test_overlapped_schedule_is_bit_identical():
     assert r.returncode == 0 and "DP_OVERLAP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-@pytest.mark.parametrize("exchange", ["allreduce", "sharded"])
+@pytest.mark.parametrize("exchange", ["allreduce", "sharded", "sh_rank1"])
 def test_bench_gpus_2_starts_two_ranks_itself(exchange):
     """`python bench.py --gpus 2` with no launcher around it (how the driver invokes --gpus 1) must start two ranks itself and
     report n_gpus = 2 (VERDICT r1 / ADVICE: it used to run ONE rank and print a 1-GPU number).  Two ranks share this box's
@@ -39,3 +39,46 @@ def test_bench_gpus_2_starts_two_ranks_itself(exchange):
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env2)
     assert r2.returncode != 0 and "refusing" in r2.stderr
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_rank1_expand_kernel_against_torch(deg):
+    """csrc/exchange.hip against the same arithmetic in torch ops (scene_utils.parallel's CPU branch): three "ranks", a third of
+    the per-rank gradients exact zeros (Gaussians without instances in that rank's view); |err| <= 1e-6 max(1, |value|)."""
+    import ctypes as C
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-slam_amd"))
+    from diff_gaussian_rasterization import _C
+    from scene_utils.sh import sh_basis, C0
+    gen = torch.Generator().manual_seed(77 + deg)
+    P, N, krest = 1000, 3, (3 + 1) ** 2 - 1
+    xyz = torch.randn(P, 3, generator=gen)
+    gathered = torch.zeros(N, P + 1, 3)
+    for r in range(N):
+        g = torch.randn(P, 3, generator=gen)
+        g[torch.rand(P, generator=gen) < 0.33] = 0.0
+        gathered[r, :P] = g
+        gathered[r, P] = 4.0 * torch.nn.functional.normalize(torch.randn(3, generator=gen), dim=0)
+    K = (deg + 1) ** 2
+    acc_dc = torch.zeros(P, 3, dtype=torch.float64)
+    acc = torch.zeros(P, krest, 3, dtype=torch.float64)
+    for r in range(N):
+        gr, cam = gathered[r, :P].double(), gathered[r, P].double()
+        acc_dc += gr
+        if K > 1:
+            d = xyz.double() - cam
+            d = d / d.norm(dim=1, keepdim=True)
+            w = sh_basis(deg, d)[:, 1:K] / C0
+            acc[:, :K - 1] += w[:, :, None] * gr[:, None, :]
+    exp_dc, exp_rest = acc_dc / N, acc / N
+    dev = "cuda"
+    out_dc = torch.full((P, 1, 3), float("nan"), device=dev)
+    out_rest = torch.full((P, krest, 3), float("nan"), device=dev)
+    xd, gd = xyz.to(dev), gathered.to(dev).contiguous()
+    _C.check(_C.lib().gsr_sh_rank1_expand(P, N, deg, krest, _C.ptr(xd), _C.ptr(gd), C.c_float(1.0 / N), _C.ptr(out_dc),
+                                          _C.ptr(out_rest), _C._stream()))
+    torch.cuda.synchronize()
+    for got, exp in ((out_dc.cpu().view(P, 3), exp_dc), (out_rest.cpu(), exp_rest)):
+        err = (got.double() - exp).abs()
+        assert bool((err <= 1e-6 * exp.abs().clamp(min=1.0)).all()), float(err.max())
+    assert not out_rest[:, K - 1:].any() if K - 1 < krest else True       # coefficients beyond the active degree: zeros

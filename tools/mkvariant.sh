@@ -9,7 +9,7 @@ mkdir -p ../../tools/variants build/var_$name
 base=${file%.hip}
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -fno-slp-vectorize $flags -c $file -o build/var_$name/$base.o
 objs=""
-for f in api preprocess sort_scan binning render ssim adam densify activations; do
+for f in api preprocess sort_scan binning render ssim adam densify activations exchange; do
   if [ "$f" = "$base" ]; then objs="$objs build/var_$name/$f.o"; else objs="$objs build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/variants/libgsr_$name.so $objs
