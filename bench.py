@@ -270,10 +270,13 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views per rank per optimizer step (gradient accumulation; default 1 = the reference's batch-1 step). "
                          "Amortises the N>1 gradient exchange and Adam over k views; value still counts view-iterations")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "visible_rows", "sharded", "sh_rank1"],
-                    help="N>1 gradient exchange: one all-reduce per leaf tensor (north-star schedule); the same restricted to the "
-                         "rows some rank saw; reduce-scatter -> Adam on a 1/N row shard -> all-gather; or sh_rank1: geometry "
-                         "all-reduced, the SH gradients rebuilt from an all-gather of dL/df_dc (DESIGN.md 5)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allreduce", "visible_rows", "sharded", "sh_rank1"],
+                    help="N>1 gradient exchange.  allreduce: one RCCL all-reduce per leaf tensor, 59 floats per Gaussian (the "
+                         "north-star schedule as written); sh_rank1: the SAME mean gradients with 2.6x fewer bytes on the links - "
+                         "the 11 geometry floats all-reduced, the 48 SH floats rebuilt on every rank from an all-gather of "
+                         "dL/df_dc + camera centres (a view's SH gradient is rank one per Gaussian); visible_rows: the "
+                         "all-reduce restricted to the rows some rank saw; sharded: reduce-scatter -> Adam on a 1/N row shard "
+                         "-> all-gather.  auto (default): sh_rank1 with one view per rank per step, else allreduce (DESIGN.md 5)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: exchange all gradients on the main stream (default overlaps the SH exchange + Adam with the next "
                          "step's geometry stages; same results, DESIGN.md 5)")
@@ -322,6 +325,9 @@ def main():
         log("no launcher detected: " + " ".join(cmd))
         sys.exit(subprocess.call(cmd))
 
+    if args.exchange == "auto":
+        args.exchange = "sh_rank1" if max(1, args.views_per_step) == 1 and args.optimizer in ("hip", "hip_fused", "torch") \
+            else "allreduce"
     torch.set_num_threads(host_threads())
     from scene_utils import init_from_env, Trainer, exchange_bytes_per_gaussian
     # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1 rehearse the N>1 path with several ranks on ONE card (no RCCL between them)
@@ -425,8 +431,9 @@ def main():
                                                     - stats_before.get("tile_local_frames", 0)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {P} Gaussians, SH degree {cfg['deg']}, "
-                               f"{W}x{H}, {len(cams)} views, one view per rank per step, all-reduce of "
-                               f"{59 if cfg['deg'] == 3 else 11 + 3 * M}-float/Gaussian grads when N>1",
+                               f"{W}x{H}, {len(cams)} views, one view per rank per step, mean of the ranks' "
+                               f"{59 if cfg['deg'] == 3 else 11 + 3 * M}-float/Gaussian gradients over RCCL when N>1 "
+                               f"(exchange: {trainer.exchange})",
                    "gaussians": P, "gaussians_final": int(model.get_xyz.shape[0]), "densify": bool(args.densify),
                    "densify_grad_threshold": args.densify_grad_threshold if args.densify else None,
                    "densify_max": args.densify_max if args.densify else None,
