@@ -14,10 +14,13 @@ timeout -k 10 300 python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O
 timeout -k 10 200 python3 bench.py $DRV --config 1 --cpu-tiles 256 > $OUT/bench_c1.json 2> $OUT/bench_c1.err
 timeout -k 10 200 python3 bench.py $DRV --config 2 --no-cpu-baseline > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 timeout -k 10 300 python3 bench.py $DRV --config 4 --views 4 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err
-timeout -k 10 300 python3 bench.py --config 5 --densify --densify-from 100 --steps 2500 --warmup 10 --no-cpu-baseline > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+# BASELINE configs[4]: the preset grows 50 k -> 500 k (bench.py: --config 5 = reference schedule from iteration 100, threshold 2e-5, stop at 500 k, 2500 steps)
+timeout -k 10 400 python3 bench.py --config 5 --warmup 10 --no-cpu-baseline > $OUT/bench_c5_growth500k.json 2> $OUT/bench_c5_growth500k.err
+timeout -k 10 300 python3 bench.py --config 5 --densify --densify-from 100 --densify-grad-threshold 0.0002 --steps 2500 --warmup 10 --no-cpu-baseline > $OUT/bench_c5_reference_threshold.json 2> $OUT/bench_c5_reference_threshold.err
 timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --optimizer hip > $OUT/bench_c3_adam_unfused.json 2> /dev/null
 timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --optimizer hip_sparse_fused > $OUT/bench_c3_sparse_fused.json 2> /dev/null
 timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --forward-mode sync > $OUT/bench_c3_sync_forward.json 2> /dev/null
+timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --forward-mode async > $OUT/bench_c3_async_forward.json 2> /dev/null
 GSR_BINNING=global timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline > $OUT/bench_c3_global_binning.json 2> /dev/null
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python3 $R/bench.py $DRV --no-cpu-baseline > $R/$OUT/stats.json 2> $R/$OUT/stats.err
