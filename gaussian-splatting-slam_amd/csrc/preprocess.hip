@@ -1086,6 +1086,8 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
   if (dL_dshs || dL_ddc) {
     // stored coefficients beyond the active degree get zero gradient
     const int stored = sh_stride + (dL_ddc ? 1 : 0);
+    // dL_dshs == NULL with dL_ddc set (the view-sharded exchange "sh_rank1": only dL/df_dc travels, the other coefficients'
+    // gradients are rebuilt from it, csrc/exchange.hip): the rest rows are neither formed nor stored
     if (STAGE) {
       // the thread has consumed its own SH row: overwrite it with the gradient row, then one flat coalesced copy-out
       for (int k = 0; k < stored; k++) {
@@ -1095,18 +1097,21 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
             float* d0 = dL_ddc + 3 * (size_t)idx;
             d0[0] = bk * g_col[0]; d0[1] = bk * g_col[1]; d0[2] = bk * g_col[2];
           }
-        } else {
+        } else if (dL_dshs) {
           float* dst = my_row + (dL_ddc ? (k - 1) : k) * 3;
           dst[0] = bk * g_col[0]; dst[1] = bk * g_col[1]; dst[2] = bk * g_col[2];
         }
       }
-      __syncthreads();
-      stage_rows_out<BT>(dL_dshs + row0 * S, rows * S, S, Sp, sh_lds);
+      if (dL_dshs) {          // (kernel argument: uniform)
+        __syncthreads();
+        stage_rows_out<BT>(dL_dshs + row0 * S, rows * S, S, Sp, sh_lds);
+      }
     } else if (active) {
       for (int k = 0; k < stored; k++) {
         const float bk = (have_sh && k < K) ? bs[k] : 0.f;
-        float* dst = dL_ddc ? ((k == 0) ? dL_ddc + 3 * (size_t)idx : dL_dshs + ((size_t)idx * sh_stride + (k - 1)) * 3)
+        float* dst = dL_ddc ? ((k == 0) ? dL_ddc + 3 * (size_t)idx : (dL_dshs ? dL_dshs + ((size_t)idx * sh_stride + (k - 1)) * 3 : nullptr))
                             : dL_dshs + ((size_t)idx * sh_stride + k) * 3;
+        if (!dst) continue;
         dst[0] = bk * g_col[0];
         dst[1] = bk * g_col[1];
         dst[2] = bk * g_col[2];
@@ -1270,7 +1275,7 @@ int gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, con
     if (stage) lds = (lds / 256) * GSR_BWD_ADAM_BT + (size_t)GSR_BWD_ADAM_BT * 19 * sizeof(float);   // rows of this kernel's workgroup
     A = *adam;
   } else {
-    stage = can_stage_sh(s, g, &lds) && gr->dL_dshs && (((uintptr_t)gr->dL_dshs & 15) == 0);
+    stage = can_stage_sh(s, g, &lds) && (gr->dL_dshs ? (((uintptr_t)gr->dL_dshs & 15) == 0) : gr->dL_ddc != nullptr);
     if (stage) lds = (lds / 256) * GSR_BWD_PLAIN_BT;
   }
 #define GSR_PRE_BWD_ARGS                                                                                              \

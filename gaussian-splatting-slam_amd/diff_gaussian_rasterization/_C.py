@@ -120,6 +120,8 @@ EXPORTS = {
                                     C.c_int64, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "gsr_sh_rank1_expand": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "gsr_sh_rank1_adam": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                    C.c_void_p, C.POINTER(gsr_fused_adam), C.c_void_p]),
     "gsr_profile_enable": (None, [C.c_int32]),
     "gsr_profile_reset": (None, []),
     "gsr_profile_read": (C.c_int32, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),

@@ -58,6 +58,15 @@ fused_backward_count = 0
 _split_rows = False
 _side_streams = {}
 _fold_stats = None
+_skip_sh_rest = False
+
+
+def skip_sh_rest_grad_in_next_backward(on=True):
+    """One-shot (view-sharded exchange "sh_rank1", scene_utils/parallel.py): the next rasterizer backward of a call that got `dc`
+    and `shs` separately forms dL/ddc only and returns None for `shs` - the ranks exchange dL/ddc and rebuild the other
+    coefficients' mean gradient from it, so this rank's own 180 B per Gaussian need not be written at all."""
+    global _skip_sh_rest
+    _skip_sh_rest = bool(on)
 
 
 def fold_densification_stats_into_next_backward(xyz_gradient_accum, denom, max_radii2D):
@@ -342,9 +351,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         def like(t, *shape):
             return torch.empty(*shape, dtype=torch.float32, device=dev) if t is not None else None
 
-        global _fused_optimizer, fused_backward_count, _fold_stats
+        global _fused_optimizer, fused_backward_count, _fold_stats, _skip_sh_rest
         with _C.on_device(dev):
             stats, _fold_stats = _fold_stats, None
+            skip_rest, _skip_sh_rest = _skip_sh_rest and dc is not None and sh is not None and colors_precomp is None, False
             if stats is not None and (stats[0].shape[0] != P or not all(t.is_contiguous() and t.dtype == torch.float32
                                                                         for t in stats)):
                 raise _C.GsrError("fold_densification_stats: statistics tensors do not match this forward's Gaussians")
@@ -358,7 +368,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 d_means3D = torch.empty(P, 3, dtype=torch.float32, device=dev)
                 d_opac = torch.empty(opacities.shape if opacities is not None else (P, 1), dtype=torch.float32, device=dev)
                 d_dc = like(dc, *(dc.shape if dc is not None else ()))
-                d_sh = like(sh, *(sh.shape if sh is not None else ()))
+                d_sh = None if skip_rest else like(sh, *(sh.shape if sh is not None else ()))
                 d_col = like(colors_precomp, P, 3)
                 d_scales = like(scales, P, 3)
                 d_rot = like(rotations, P, 4)

@@ -102,7 +102,40 @@ class GradBucket:
         return int(idx.numel())
 
 
-def rank1_sh_exchange(xyz, f_dc, f_rest, cam_center, sh_degree: int, world: int, group=None):
+def _fused_sh_adam_args(optimizer, f_dc, f_rest):
+    """gsr_fused_adam for the f_dc / f_rest groups of a dense FusedAdam (their step counters advance), or None."""
+    from diff_gaussian_rasterization import _C, FusedAdam
+    if not isinstance(optimizer, FusedAdam):
+        return None
+    groups = {g.get("name"): g for g in optimizer.param_groups}
+    if "f_dc" not in groups or "f_rest" not in groups or groups["f_dc"]["params"][0] is not f_dc or \
+            groups["f_rest"]["params"][0] is not f_rest:
+        return None
+    fa = _C.gsr_fused_adam()
+    keep = []
+    for i, (name, p) in ((1, ("f_dc", f_dc)), (2, ("f_rest", f_rest))):
+        if not p.is_contiguous() or p.dtype != torch.float32:
+            return None
+        st = optimizer.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        keep.append(st)
+    for i, (name, p) in ((1, ("f_dc", f_dc)), (2, ("f_rest", f_rest))):
+        st = optimizer.state[p]
+        st["step"] += 1
+        fa.exp_avg[i] = st["exp_avg"].data_ptr() if p.numel() else None
+        fa.exp_avg_sq[i] = st["exp_avg_sq"].data_ptr() if p.numel() else None
+        fa.lr[i] = float(groups[name]["lr"])
+        fa.step[i] = int(st["step"])
+    g0 = optimizer.param_groups[0]
+    fa.beta1, fa.beta2, fa.eps = float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"])
+    fa.sparse = 0
+    return fa, keep
+
+
+def rank1_sh_exchange(xyz, f_dc, f_rest, cam_center, sh_degree: int, world: int, group=None, optimizer=None):
     """Exchange of the two SH gradient tensors for ONE view per rank per step (`exchange="sh_rank1"`).
 
     A view's SH gradient is rank one per Gaussian: dL/dsh[k][c] = basis_k(dir) * dL/drgb_c (SURVEY.md A.7 iv), and band 0's
@@ -112,13 +145,28 @@ def rank1_sh_exchange(xyz, f_dc, f_rest, cam_center, sh_degree: int, world: int,
     order (csrc/exchange.hip on the HIP device; the same arithmetic in torch ops on the CPU for the gloo tests): identical bits
     on every rank; against the all-reduce schedule the values agree to fp32 rounding of the individual products
     ((b / C0) (C0 g) instead of b g, and a fixed instead of the collective's summation order).
-    `xyz`: the positions the forwards saw (call before the optimizer moves them).  Leaves the means in f_dc.grad / f_rest.grad."""
+    `xyz`: the positions the forwards saw (call before the optimizer moves them).  Leaves the means in f_dc.grad / f_rest.grad -
+    or, with `optimizer` (a dense FusedAdam whose f_dc / f_rest groups are these tensors, HIP device), applies that optimizer's
+    step to the two tensors in the rebuilding kernel itself (gsr_sh_rank1_adam: the rebuilt 192 B per Gaussian are never
+    written; bit-identical to rebuild + optimizer.step(only=("f_dc", "f_rest"))), clears both .grad and returns True."""
     P = int(xyz.shape[0])
     krest = int(f_rest.shape[1]) if f_rest.numel() else 0
     g = f_dc.grad if f_dc.grad is not None else torch.zeros_like(f_dc)
     mine = torch.cat((g.reshape(P, 3), cam_center.reshape(1, 3).to(g)), dim=0).contiguous()        # [P + 1, 3]
     gathered = torch.empty(world * (P + 1), 3, dtype=g.dtype, device=g.device)
     dist.all_gather_into_tensor(gathered, mine, group=group)
+    if g.is_cuda and optimizer is not None:
+        fused = _fused_sh_adam_args(optimizer, f_dc, f_rest)
+        if fused is not None:
+            import ctypes as C
+            from diff_gaussian_rasterization import _C
+            with _C.on_device(g.device):
+                _C.check(_C.lib().gsr_sh_rank1_adam(P, world, int(sh_degree), krest, _C.ptr(xyz.detach().contiguous()),
+                                                    _C.ptr(gathered), C.c_float(1.0 / world), _C.ptr(f_dc.data),
+                                                    _C.ptr(f_rest.data) if krest else None, C.byref(fused[0]), _C._stream()))
+            f_dc.grad = None
+            f_rest.grad = None
+            return True
     out_dc = torch.empty_like(f_dc)
     out_rest = torch.empty_like(f_rest)
     if g.is_cuda:
@@ -146,6 +194,7 @@ def rank1_sh_exchange(xyz, f_dc, f_rest, cam_center, sh_degree: int, world: int,
         out_rest.copy_(acc * (1.0 / world))
     f_dc.grad = out_dc
     f_rest.grad = out_rest
+    return False
 
 
 def exchange_bytes_per_gaussian(exchange: str, world: int, sh_coeffs: int = 16, visible_fraction: float = 1.0):

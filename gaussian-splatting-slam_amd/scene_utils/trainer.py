@@ -86,6 +86,8 @@ class Trainer:
         self.iteration = 0
         self._one = None                 # cached dL/dloss = 1 for loss.backward()
         self.last = {}
+        self._rank1_fused = False
+        self.rank1_fuse_adam = True      # exchange "sh_rank1": let the rebuilding kernel apply the SH groups' Adam step (dense HIP Adam)
         self._ticket_view = {}           # forward mode "async": rasterizer ticket -> view of the frames still unverified
         self.rerun_views = 0             # ... and how many truncated frames were run again
 
@@ -142,9 +144,20 @@ class Trainer:
             if fold:
                 import diff_gaussian_rasterization as dgr
                 dgr.fuse_optimizer_into_next_backward(self.optimizer, split_rows=self.split_rows)
+            # exchange "sh_rank1" with the dense HIP Adam: this rank's dL/df_rest is not exchanged (rebuilt from the ranks' dL/df_dc)
+            # and, unless a densification sits between backward and step, the two SH groups' Adam step rides in the rebuilding
+            # kernel: the backward need not write those 180 B per Gaussian at all
+            self._rank1_fused = (self.rank1_fuse_adam and self.exchange == "sh_rank1" and self.world > 1 and len(views) == 1 and
+                                 self.optimizer_kind == "hip" and self.separate_sh and self.model.get_xyz.is_cuda and
+                                 not self._densify_due(self.iteration + 1))
+            if self._rank1_fused:
+                import diff_gaussian_rasterization as dgr
+                dgr.skip_sh_rest_grad_in_next_backward()
             if self._one is None or self._one.device != loss.device:
                 self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
             loss.backward(gradient=self._one)          # .grad accumulates; (a cached seed: no fill launch per step)
+            if self._rank1_fused:
+                dgr.skip_sh_rest_grad_in_next_backward(False)     # (a renderer that did not take the hand-off leaves it set)
             folded = False
             if fold:
                 folded = not dgr.fuse_pending()
@@ -187,7 +200,8 @@ class Trainer:
             if self.bucket is not None and rank1_cam is not None:
                 m = self.model
                 self.bucket.all_reduce_mean(self.world, params=[m._xyz, m._opacity, m._scaling, m._rotation])
-                rank1_sh_exchange(m._xyz, m._features_dc, m._features_rest, rank1_cam, m.active_sh_degree, self.world)
+                rank1_sh_exchange(m._xyz, m._features_dc, m._features_rest, rank1_cam, m.active_sh_degree, self.world,
+                                  optimizer=self.optimizer if self._rank1_fused else None)
             elif self.bucket is not None:
                 self.bucket.all_reduce_mean(self.world, visible=vis.get() if self.exchange == "visible_rows" else None)
             if self.densify is not None:
@@ -272,10 +286,15 @@ class Trainer:
                 snap = torch.cuda.Event()
                 snap.record(side)
                 main.wait_event(snap)
-                rank1_sh_exchange(xyz_seen, m._features_dc, m._features_rest, rank1_cam, m.active_sh_degree, self.world)
+                stepped = rank1_sh_exchange(xyz_seen, m._features_dc, m._features_rest, rank1_cam, m.active_sh_degree,
+                                            self.world, optimizer=self.optimizer if self._rank1_fused else None)
+                if stepped:
+                    sh_names = ()                     # the rebuilding kernel applied the SH groups' step itself
             elif self.bucket is not None:
                 self.bucket.all_reduce_mean(self.world, params=sh)
-            if self.optimizer_kind == "hip_sparse":
+            if not sh_names:
+                pass
+            elif self.optimizer_kind == "hip_sparse":
                 self.optimizer.step(vis, radii.shape[0], only=sh_names)
             else:
                 self.optimizer.step(only=sh_names)

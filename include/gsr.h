@@ -87,7 +87,8 @@ typedef struct gsr_grads {
   float* dL_dmeans2D;   /* [P,3] screen-space gradient in NDC units, z = 0 (consumed by
                            scene/gaussian_model.py:431-433 add_densification_stats) */
   float* dL_ddc;        /* [P,1,3] or NULL */
-  float* dL_dshs;       /* [P,sh_coeffs,3] or NULL */
+  float* dL_dshs;       /* [P,sh_coeffs,3] or NULL (NULL although `shs` was given: allowed with `dc` - only dL_ddc is formed,
+                           the view-sharded "sh_rank1" exchange rebuilds the rest from it) */
   float* dL_dcolors;    /* [P,3] or NULL (colors_precomp) */
   float* dL_dopacities; /* [P] */
   float* dL_dscales;    /* [P,3] or NULL */
@@ -345,6 +346,11 @@ int gsr_gaussian_activations_backward(int32_t P, const float* raw_rotation, cons
  * the positions the forwards saw.  Coefficients beyond the active degree get zeros. */
 int gsr_sh_rank1_expand(int32_t P, int32_t n_ranks, int32_t sh_degree, int32_t sh_coeffs_rest, const float* means3D,
                         const float* gathered, float scale, float* dL_ddc_mean, float* dL_dsh_rest_mean, void* stream);
+/* gsr_sh_rank1_expand followed by the dense Adam update (torch.optim.Adam semantics) of f_dc and f_rest, in ONE kernel: the
+ * rebuilt gradients are never written to memory.  `opt`: groups 1 (f_dc) and 2 (f_rest) of a gsr_fused_adam are used (moments,
+ * lr, 1-based step AFTER this update; sparse must be 0).  Bit-identical to gsr_sh_rank1_expand + gsr_adam_step on those tensors. */
+int gsr_sh_rank1_adam(int32_t P, int32_t n_ranks, int32_t sh_degree, int32_t sh_coeffs_rest, const float* means3D,
+                      const float* gathered, float scale, float* f_dc, float* f_rest, const gsr_fused_adam* opt, void* stream);
 
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline block).  A measurement aid, process-
  * global and meant for ONE host thread driving the library at a time: enabling it while several host threads launch

@@ -15,7 +15,7 @@ from scene_utils import init_from_env, shard_views, Trainer, GaussianModel, make
 from gaussian_renderer import render, PipelineParams  # noqa: E402
 
 
-def run(overlap, optimizer, rank, world, steps=6, exchange="allreduce"):
+def run(overlap, optimizer, rank, world, steps=6, exchange="allreduce", fuse_rank1=True):
     dev = "cuda:0"
     raw = make_gaussians(3000, 2, seed=12, scale_factor=0.8)
     cams = fibonacci_cameras(4, 128, 80, seed=13, device=dev)
@@ -28,6 +28,7 @@ def run(overlap, optimizer, rank, world, steps=6, exchange="allreduce"):
     tr = Trainer(model, cams, gts, render, pipe, bg, world=world, rank=rank, optimizer=optimizer, separate_sh=True,
                  overlap_comm=overlap, exchange=exchange)
     assert tr.overlap_comm == overlap and tr.exchange == exchange
+    tr.rank1_fuse_adam = fuse_rank1
     tr.enable_densification(extent=4.4, from_iter=2, until_iter=100, interval=4, opacity_reset_interval=50, grad_threshold=2e-5)
     mine = shard_views(len(cams), rank, world)
     for it in range(steps):
@@ -55,6 +56,9 @@ def main():
     ref = run(False, "hip", rank, world)
     plain = run(False, "hip", rank, world, exchange="sh_rank1")
     over = run(True, "hip", rank, world, exchange="sh_rank1")
+    unfused = run(True, "hip", rank, world, exchange="sh_rank1", fuse_rank1=False)    # rebuild -> .grad -> optimizer.step()
+    for a, b in zip(over, unfused):
+        assert a.shape == b.shape and torch.equal(a, b), "the Adam step folded into the rank-one rebuild changed the result"
     for a, b, c in zip(plain, over, ref):
         assert a.shape == b.shape and torch.equal(a, b), "overlapped sh_rank1 schedule changed the result"
         assert a.shape == c.shape and torch.allclose(a, c, atol=1e-6, rtol=1e-4), float((a - c).abs().max())

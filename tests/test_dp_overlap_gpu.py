@@ -82,3 +82,46 @@ def test_sh_rank1_expand_kernel_against_torch(deg):
         err = (got.double() - exp).abs()
         assert bool((err <= 1e-6 * exp.abs().clamp(min=1.0)).all()), float(err.max())
     assert not out_rest[:, K - 1:].any() if K - 1 < krest else True       # coefficients beyond the active degree: zeros
+
+
+def test_sh_rank1_adam_kernel_is_expand_plus_adam_bit_for_bit():
+    """gsr_sh_rank1_adam (rebuild + dense Adam of f_dc / f_rest in one kernel) against gsr_sh_rank1_expand followed by
+    FusedAdam.step on the two tensors, three steps (so the moments matter): parameters and both moments bit for bit."""
+    import ctypes as C
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-slam_amd"))
+    from diff_gaussian_rasterization import _C, FusedAdam
+    from scene_utils.parallel import _fused_sh_adam_args
+    dev, P, N, deg, krest = "cuda", 3001, 4, 3, 15
+    gen = torch.Generator().manual_seed(91)
+    xyz = torch.randn(P, 3, generator=gen).to(dev)
+
+    def make():
+        g2 = torch.Generator().manual_seed(92)
+        f_dc = torch.nn.Parameter(torch.randn(P, 1, 3, generator=g2).to(dev))
+        f_rest = torch.nn.Parameter(torch.randn(P, krest, 3, generator=g2).to(dev))
+        opt = FusedAdam([{"params": [f_dc], "lr": 0.0025, "name": "f_dc"}, {"params": [f_rest], "lr": 0.000125, "name": "f_rest"}],
+                        lr=0.0, eps=1e-15)
+        return f_dc, f_rest, opt
+    a_dc, a_rest, a_opt = make()
+    b_dc, b_rest, b_opt = make()
+    lib = _C.lib()
+    for it in range(3):
+        gathered = torch.randn(N, P + 1, 3, generator=gen)
+        gathered[:, :P][torch.rand(N, P, generator=gen) < 0.3] = 0.0
+        gathered = gathered.to(dev).contiguous()
+        # (a) expand -> .grad -> FusedAdam.step
+        a_dc.grad, a_rest.grad = torch.empty_like(a_dc), torch.empty_like(a_rest)
+        _C.check(lib.gsr_sh_rank1_expand(P, N, deg, krest, _C.ptr(xyz), _C.ptr(gathered), C.c_float(1.0 / N), _C.ptr(a_dc.grad),
+                                         _C.ptr(a_rest.grad), _C._stream()))
+        a_opt.step()
+        # (b) one kernel
+        fa, keep = _fused_sh_adam_args(b_opt, b_dc, b_rest)
+        _C.check(lib.gsr_sh_rank1_adam(P, N, deg, krest, _C.ptr(xyz), _C.ptr(gathered), C.c_float(1.0 / N), _C.ptr(b_dc.data),
+                                       _C.ptr(b_rest.data), C.byref(fa), _C._stream()))
+    torch.cuda.synchronize()
+    for x, y, ox, oy in ((a_dc, b_dc, a_opt, b_opt), (a_rest, b_rest, a_opt, b_opt)):
+        assert torch.equal(x.data, y.data)
+        assert torch.equal(ox.state[x]["exp_avg"], oy.state[y]["exp_avg"])
+        assert torch.equal(ox.state[x]["exp_avg_sq"], oy.state[y]["exp_avg_sq"])
+        assert int(ox.state[x]["step"]) == int(oy.state[y]["step"]) == 3
