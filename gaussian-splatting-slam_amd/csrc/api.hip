@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <map>
 #include <mutex>
@@ -356,18 +357,42 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
 // Waits until the count of the forward just enqueued by THIS host thread has reached its pinned slot (`ev` was recorded right
 // behind the kernel / copy that delivers it - the rest of the forward may still be queued behind it) and decodes it.
 #define GSR_COUNT_VALID (1ull << 63)
+// Never a wait without a bound: the host POLLS - the count word the scan kernel stores into pinned memory, or the event behind
+// the 16-byte copy - first spinning (the count is ~50 us of device time away once the frame has started), then with short sleeps,
+// and gives up loudly after GSR_COUNT_TIMEOUT_S seconds (default 120; a device fault aborts the process long before).
 static int64_t wait_for_count(uint32_t* host, hipEvent_t ev, bool early_word) {
-  int rc;
-  if ((rc = gsr_check(hipEventSynchronize(ev), "wait for num_rendered"))) return rc;
+  static const double limit_s = getenv("GSR_COUNT_TIMEOUT_S") ? atof(getenv("GSR_COUNT_TIMEOUT_S")) : 120.0;
+  volatile unsigned long long* w = (volatile unsigned long long*)(host + 8);
+  unsigned long long v = 0;
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned long it = 0;; it++) {
+    if (early_word) {
+      v = *w;
+      if (v & GSR_COUNT_VALID) break;
+    } else {
+      const hipError_t e = hipEventQuery(ev);
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) return gsr_check(e, "wait for num_rendered");
+      (void)hipGetLastError();
+    }
+    if (it >= (early_word ? 20000ul : 200ul)) {
+      struct timespec nap = {0, 2000};
+      nanosleep(&nap, nullptr);
+      if ((it & 255ul) == 0) {
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > limit_s) {
+          gsr_set_error("num_rendered did not arrive within %.0f s (device hung, or the stream is blocked behind an event that "
+                        "never completes)", limit_s);
+          return GSR_ERR_HIP;
+        }
+      }
+    }
+  }
   unsigned long long total;
   bool culled;
   if (early_word) {
-    volatile unsigned long long* w = (volatile unsigned long long*)(host + 8);
-    unsigned long long v = *w;
-    // (the event completed behind the storing kernel, so the word is there; the bounded re-read only covers a write still
-    // travelling through the host bridge)
-    for (int spin = 0; !(v & GSR_COUNT_VALID) && spin < (1 << 22); spin++) v = *w;
-    if (!(v & GSR_COUNT_VALID)) { gsr_set_error("num_rendered did not arrive in the pinned slot"); return GSR_ERR_HIP; }
     culled = (v >> 62) & 1ull;
     total = v & ((1ull << 62) - 1ull);
   } else {
