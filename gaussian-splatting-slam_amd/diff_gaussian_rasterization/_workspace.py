@@ -109,6 +109,23 @@ class Lease:
             pass
 
 
+WAIT_LIMIT_S = float(os.environ.get("GSR_COUNT_TIMEOUT_S", "120"))
+
+
+def _wait_bounded(ev, what):
+    """`ev.synchronize()` with a bound: no host wait of this module may sit forever behind a device that stopped making progress
+    (the native side bounds its own wait for the count the same way, api.hip wait_for_count)."""
+    import time
+    t0 = time.monotonic()
+    spins = 0
+    while not ev.query():
+        spins += 1
+        if spins > 2000:
+            time.sleep(50e-6)
+            if time.monotonic() - t0 > WAIT_LIMIT_S:
+                raise _C.GsrError(f"gsr: {what} did not arrive within {WAIT_LIMIT_S:.0f} s (device hung?)")
+
+
 class Pool:
     def __init__(self, device):
         self.device = device
@@ -175,7 +192,7 @@ class Pool:
         while self.pending:
             ev, status, cap, key, ticket, verified = self.pending[0]
             if wait:
-                ev.synchronize()
+                _wait_bounded(ev, f"the status of frame {ticket}")
             elif not ev.query():
                 break
             self.pending.popleft()

@@ -1,0 +1,98 @@
+"""Host-side bookkeeping of the speculative forward (diff_gaussian_rasterization/_workspace.py) without a GPU: capacity
+estimates, the first-frame guess, per-frame overflow reports of the unverified mode, mode switching.  Events and pinned status
+slots are stood in for by plain objects; no library call is made."""
+import warnings
+
+import pytest
+import torch
+
+
+class _Ev:
+    def __init__(self, done=True):
+        self.done = done
+
+    def query(self):
+        return self.done
+
+    def synchronize(self):
+        self.done = True
+
+
+def _pool():
+    from diff_gaussian_rasterization import _workspace as ws
+    p = ws.Pool(torch.device("cpu"))
+    p.status_slot = lambda: torch.zeros(4, dtype=torch.int64)          # (the real one pins the memory)
+    return ws, p
+
+
+def test_modes_and_default():
+    import os
+    from diff_gaussian_rasterization import _workspace as ws
+    old = ws.forward_mode()
+    try:
+        if "GSR_FORWARD_MODE" not in os.environ:
+            assert old == "exact"
+        for m in ("exact", "async", "sync"):
+            ws.set_forward_mode(m)
+            assert ws.forward_mode() == m
+        with pytest.raises(ValueError):
+            ws.set_forward_mode("fast")
+    finally:
+        ws.set_forward_mode(old)
+
+
+def test_first_frame_guess_then_measured_capacity_with_headroom():
+    ws, p = _pool()
+    key = (100_000, 1920, 1080)
+    guess = p.capacity_for_frame(key)
+    assert guess >= ws.FIRST_GUESS_PER_GAUSSIAN * key[0] and guess % 4096 == 0 and key not in p.capacity
+    p.note(key, 1_340_000)
+    cap = p.capacity[key]
+    assert cap >= int(1_340_000 * ws.HEADROOM) and cap % 4096 == 0 and p.capacity_for_frame(key) == cap
+    p.note(key, 1_400_000)                      # within the headroom: the estimate holds
+    assert p.capacity[key] == cap
+    p.note(key, int(cap / 1.05))                # closer than 10 % to the capacity: raised
+    assert p.capacity[key] > cap
+    assert p.capacity_for_frame((3, 16, 16)) == ws.MIN_CAPACITY
+
+
+def test_unverified_frames_are_reported_per_ticket_and_verified_ones_are_not():
+    ws, p = _pool()
+    key = (1000, 64, 64)
+    p.capacity[key] = 20000
+
+    def frame(R, ticket, verified, done=True, longest=0):
+        st = p.status_slot()
+        st[0], st[1], st[2] = 0, R, longest
+        p.pending.append((_Ev(done), st, 20000, key, ticket, verified))
+    frame(15000, 1, False)
+    frame(50000, 2, False)                      # truncated
+    frame(70000, 3, True)                       # verified by the forward itself (it re-rendered): not an overflow
+    frame(90000, 4, False, done=False)          # status not there yet
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        p.poll()
+    assert [str(x.message).split()[2] for x in w] == ["2"]           # "gsr: frame 2 ..."
+    assert p.stats["overflow_frames"] == 1 and p.take_overflowed() == [2] and p.take_overflowed() == []
+    assert len(p.pending) == 1 and p.capacity[key] >= 50000
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        p.poll(wait=True)
+    assert p.take_overflowed() == [4] and p.stats["overflow_frames"] == 2 and not p.pending
+    assert p.stats["num_rendered"] == 90000
+
+
+def test_long_lists_send_a_shape_back_to_the_global_binning_form():
+    ws, p = _pool()
+    key = (9000, 96, 64)
+    if ws._BINNING != "tile":
+        pytest.skip("GSR_BINNING=global")
+    assert ws.tile_local_binning(p, key)
+    st = p.status_slot()
+    st[1], st[2] = 5000, 5000
+    p.capacity[key] = 16384
+    p.pending.append((_Ev(), st, 16384, key, 1, True))
+    p.poll()
+    assert p.longest_list[key] == 5000 and not ws.tile_local_binning(p, key)
+    p.forget_estimates()
+    assert ws.tile_local_binning(p, key) and not p.capacity
