@@ -40,6 +40,8 @@ def check_grads(out, ref, rel=GRAD_REL):
     for k, g_ref in ref["grads"].items():
         g = out["grads"][k]
         assert g.shape == g_ref.shape, k
+        if g_ref.numel() == 0:          # (SH degree 0 in the dc + rest call form: an empty rest tensor)
+            continue
         assert torch.isfinite(g).all(), k
         if float(g_ref.abs().max()) == 0.0:
             assert float(g.abs().max()) == 0.0, k
