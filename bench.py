@@ -333,6 +333,17 @@ def main():
     # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1 rehearse the N>1 path with several ranks on ONE card (no RCCL between them)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     rank, world, local = init_from_env(backend)
+    # BENCH_SINGLE_RANK_GROUP=1 (with --gpus 1): a process group of ONE rank, and the Trainer runs the whole N > 1 schedule on it
+    # (every collective through RCCL, side stream, exchange kernels): the rehearsal of that path on a one-GPU box.  Not a
+    # scaling number: the line it prints says n_gpus 1 and "single_rank_group": true.
+    single_rank_group = world == 1 and os.environ.get("BENCH_SINGLE_RANK_GROUP") == "1"
+    if single_rank_group:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend=backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     if os.environ.get("BENCH_SHARE_GPU"):
         local = 0
     log(f"rank {os.environ.get('RANK', '0')} start; host threads {host_threads()} (cpu_count {os.cpu_count()})")
@@ -354,7 +365,7 @@ def main():
                       loss=args.loss, separate_sh=not args.concat_sh, depth_targets=depth_gts,
                       depth_weight=1.0 if depth_gts is not None else 0.0,
                       overlap_comm=False if args.no_overlap else (True if args.overlap else None),
-                      exchange=args.exchange)
+                      exchange=args.exchange, single_rank_group=single_rank_group)
     trainer.split_rows = bool(args.split_rows)
     if args.densify:
         # cameras_extent of the reference = 1.1 x radius of the camera centres (scene/dataset_readers.py getNerfppNorm)
@@ -438,7 +449,8 @@ def main():
                    "densify_grad_threshold": args.densify_grad_threshold if args.densify else None,
                    "densify_max": args.densify_max if args.densify else None,
                    "sh_degree": cfg["deg"], "width": W, "height": H, "views": len(cams),
-                   "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}",
+                   "antialiasing": bool(cfg.get("antialiasing", False)), "parallelism": f"view-dp{world}", 
+                   **({"single_rank_group": True} if single_rank_group else {}),
                    "views_per_rank_per_step": k, "overlap_comm": bool(trainer.overlap_comm), "exchange": trainer.exchange,
                    "exchange_bytes_per_gaussian_received": round(exchange_bytes_per_gaussian(trainer.exchange, world, M), 1)
                                                             if world > 1 else 0,
@@ -447,7 +459,11 @@ def main():
                                  "hip_fused": "Adam (torch.optim.Adam semantics) folded into the rasterizer backward",
                                  "hip_sparse": "SparseGaussianAdam (HIP)",
                                  "hip_sparse_fused": "SparseGaussianAdam folded into the rasterizer backward",
-                                 "torch": "torch.optim.Adam"}[args.optimizer]},
+                                 "torch": "torch.optim.Adam"}[args.optimizer if not trainer.distributed else
+                                                              args.optimizer.replace("_fused", "")] +
+                                (" (SH groups: step applied by the sh_rank1 rebuilding kernel)"
+                                 if trainer.distributed and trainer.exchange == "sh_rank1" and trainer.rank1_fuse_adam
+                                 and args.optimizer in ("hip", "hip_fused") and k == 1 else "")},
     }
 
     # ---- untimed extras (rank 0 reports) ----
@@ -541,7 +557,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or single_rank_group:
         dist.barrier()
         dist.destroy_process_group()
 

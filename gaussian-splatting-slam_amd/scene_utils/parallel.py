@@ -38,6 +38,12 @@ def shard_views(n_views: int, rank: int, world: int, epoch_perm=None):
     return ids[rank::world]
 
 
+def _nothing_to_exchange(world: int) -> bool:
+    """One rank and no process group.  (One rank WITH a group - the single-GPU rehearsal of the N > 1 schedule, Trainer
+    single_rank_group - runs the collectives: a mean over one rank.)"""
+    return world <= 1 and not (dist.is_available() and dist.is_initialized())
+
+
 class GradBucket:
     """Sums the gradients of `params` over ranks and leaves the MEAN in `.grad`.
 
@@ -52,7 +58,7 @@ class GradBucket:
     def all_reduce_mean(self, world: int, group=None, params=None, visible=None):
         """`params`: optional subset of the bucket's parameters to exchange in this call.
         `visible` (bool[P], this rank's visibility filter): exchange only the rows some rank saw (`all_reduce_visible_rows`)."""
-        if world <= 1:
+        if _nothing_to_exchange(world):
             return
         if visible is not None:
             return self.all_reduce_visible_rows(world, visible, group=group, params=params)
@@ -284,7 +290,7 @@ class ShardedStep:
 
 def reduce_densification_stats(xyz_gradient_accum, denom, max_radii2D, world: int, group=None):
     """Per-view statistics (reference scene/gaussian_model.py:431-433, train.py:159) -> identical on all ranks."""
-    if world <= 1:
+    if _nothing_to_exchange(world):
         return
     dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=group)

@@ -24,14 +24,17 @@ class _LazyVisibility:
 class Trainer:
     def __init__(self, model, cameras, gt_images, render_fn, pipe, bg, lambda_dssim=0.2, world=1, rank=0,
                  optimizer="hip", loss="hip", depth_targets=None, depth_weight=0.0, separate_sh=False, overlap_comm=None,
-                 exchange="allreduce"):
+                 exchange="allreduce", single_rank_group=False):
         """optimizer: "hip" (one-launch HIP Adam, default-optimizer semantics), "hip_sparse" (SparseGaussianAdam, the
         reference's accelerated choice) or "torch" (torch.optim.Adam; CPU tests).  loss: "hip" (fused SSIM kernels) or a
-        callable (image, gt_image, lambda_dssim) -> scalar (the CPU tests hand in the oracle's pure-PyTorch loss)."""
+        callable (image, gt_image, lambda_dssim) -> scalar (the CPU tests hand in the oracle's pure-PyTorch loss).
+        single_rank_group: world == 1 with an initialised process group of one rank: run the N > 1 schedule anyway (every
+        collective, side stream and exchange kernel; the mean over one rank) - the rehearsal of that path on ONE GPU over RCCL."""
         self.model, self.cameras, self.gt_images = model, cameras, gt_images
         self.render_fn, self.pipe, self.bg = render_fn, pipe, bg
         self.lambda_dssim = lambda_dssim
         self.world, self.rank = world, rank
+        self.distributed = world > 1 or bool(single_rank_group)
         # "hip_fused" / "hip_sparse_fused": the same two optimizers with their step folded into the rasterizer's backward
         # (gsr_backward_adam) whenever nothing sits between backward and step: one rank, one view per step, no densification
         # due.  Same arithmetic, bit for bit; the 59 floats per Gaussian of gradients never leave the kernel.
@@ -47,7 +50,7 @@ class Trainer:
         if not callable(loss) and loss != "hip":
             raise ValueError("loss: 'hip' or a callable (the pure-PyTorch loss is test infrastructure: oracle/loss_oracle.py)")
         self.loss_fn = loss if callable(loss) else training_loss_fused
-        self.bucket = GradBucket(model.parameters()) if world > 1 else None
+        self.bucket = GradBucket(model.parameters()) if self.distributed else None
         # N > 1 gradient exchange: "allreduce" (one all-reduce per leaf, every rank runs the whole update),
         # "visible_rows" (the same, restricted to the rows some rank saw), "sharded" (reduce-scatter -> Adam on a 1/N row shard
         # -> all-gather of the parameters; dense optimizers, no densification yet: the moments live per shard)
@@ -55,7 +58,7 @@ class Trainer:
         # all-gather of dL/df_dc + camera centres (parallel.rank1_sh_exchange): 161 instead of 413 B per Gaussian at N = 8
         if exchange not in ("allreduce", "visible_rows", "sharded", "sh_rank1"):
             raise ValueError(exchange)
-        self.exchange = exchange if world > 1 else "allreduce"
+        self.exchange = exchange if self.distributed else "allreduce"
         self.sharded = None
         if self.exchange == "sharded":
             if optimizer not in ("hip", "torch"):
@@ -78,7 +81,7 @@ class Trainer:
             self.exchange in ("allreduce", "sh_rank1")
         # default: on for N > 1.  On one GPU it can be requested, but it buys nothing (measured 2.22 vs 2.21 ms/step at C3: the
         # Adam kernel fills the machine, the small geometry kernels just queue behind it); what it hides is COMMUNICATION.
-        self.overlap_comm = (can_overlap and world > 1) if overlap_comm is None else (bool(overlap_comm) and can_overlap)
+        self.overlap_comm = (can_overlap and self.distributed) if overlap_comm is None else (bool(overlap_comm) and can_overlap)
         self.side_stream = torch.cuda.Stream(device=model.get_xyz.device) if self.overlap_comm else None
         if self.overlap_comm:
             self.optimizer.init_state()      # moments live in the main stream's pool, never the side stream's
@@ -139,7 +142,7 @@ class Trainer:
                 import diff_gaussian_rasterization as dgr
                 dgr.fold_densification_stats_into_next_backward(self.model.xyz_gradient_accum, self.model.denom,
                                                                 self.model.max_radii2D)
-            fold = self.fuse_step and self.world == 1 and len(views) == 1 and not self._densify_due(self.iteration + 1) \
+            fold = self.fuse_step and not self.distributed and len(views) == 1 and not self._densify_due(self.iteration + 1) \
                 and self.separate_sh
             if fold:
                 import diff_gaussian_rasterization as dgr
@@ -147,7 +150,7 @@ class Trainer:
             # exchange "sh_rank1" with the dense HIP Adam: this rank's dL/df_rest is not exchanged (rebuilt from the ranks' dL/df_dc)
             # and, unless a densification sits between backward and step, the two SH groups' Adam step rides in the rebuilding
             # kernel: the backward need not write those 180 B per Gaussian at all
-            self._rank1_fused = (self.rank1_fuse_adam and self.exchange == "sh_rank1" and self.world > 1 and len(views) == 1 and
+            self._rank1_fused = (self.rank1_fuse_adam and self.exchange == "sh_rank1" and self.distributed and len(views) == 1 and
                                  self.optimizer_kind == "hip" and self.separate_sh and self.model.get_xyz.is_cuda and
                                  not self._densify_due(self.iteration + 1))
             if self._rank1_fused:
@@ -178,7 +181,7 @@ class Trainer:
         self.last = dict(loss=loss.detach(), image=image.detach(), radii=radii)
         if len(views) == 1 and folded and self.densify is None:
             return self.last            # parameters already updated by the backward; no gradient was stored, nothing to zero
-        if self.world > 1 and self.optimizer_kind == "hip_sparse":
+        if self.distributed and self.optimizer_kind == "hip_sparse":
             # SparseGaussianAdam updates the rows visible in "the" view; with views sharded over ranks that is the UNION of
             # the ranks' visibility masks (a Gaussian seen by any rank has a non-zero averaged gradient) - otherwise the
             # replicas would drift apart
@@ -231,7 +234,7 @@ class Trainer:
             v = self._ticket_view.pop(t, None)
             if v is None:
                 continue
-            if self.fuse_step and self.world == 1:
+            if self.fuse_step and not self.distributed:
                 # the folded step that did not happen was counted on the host: the bias correction must not see it
                 for st in self.optimizer.state.values():
                     if "step" in st and float(st["step"]) > 0:

@@ -19,6 +19,17 @@ def test_overlapped_schedule_is_bit_identical():
     assert r.returncode == 0 and "DP_OVERLAP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+def test_every_exchange_runs_on_rccl_with_one_rank():
+    """The collectives of the N > 1 schedule on REAL RCCL (backend "nccl"; one rank, because RCCL wants one device per rank and
+    the box has one): all-reduce AVG in place on the six leaf gradients, uint8 MAX, all_gather_into_tensor (also in place on a
+    slice of its own output), reduce_scatter_tensor, async work issued from a side stream - each schedule must give the plain
+    single-GPU run's parameters (tests/rccl_single_rank_worker.py)."""
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank_worker.py")]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "RCCL_SINGLE_RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 @pytest.mark.parametrize("exchange", ["allreduce", "sharded", "sh_rank1"])
 def test_bench_gpus_2_starts_two_ranks_itself(exchange):
     """`python bench.py --gpus 2` with no launcher around it (how the driver invokes --gpus 1) must start two ranks itself and
