@@ -61,6 +61,36 @@ _fold_stats = None
 _skip_sh_rest = False
 
 
+_last_dc_grad = None       # (data_ptr, numel) of the dc gradient the most recent backward returned
+GRAD_ARENA_ALIGN = 64      # floats: every gradient tensor of the arena starts on a 256-byte boundary
+
+
+def _grad_arena(dev, parts):
+    """parts: ((shape | None, spare floats behind it), ...) -> one tensor per part (None where the shape is None), all views of
+    ONE float32 allocation, in order, each starting on a GRAD_ARENA_ALIGN boundary."""
+    offs, total = [], 0
+    for shape, spare in parts:
+        if shape is None:
+            offs.append(None)
+            continue
+        n = 1
+        for d in shape:
+            n *= int(d)
+        offs.append((total, n))
+        total += -(-(n + spare) // GRAD_ARENA_ALIGN) * GRAD_ARENA_ALIGN
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    return [None if o is None else flat[o[0]:o[0] + o[1]].view(shape) for o, (shape, _) in zip(offs, parts)]
+
+
+def dc_grad_tail_row(g):
+    """`g`: a dc gradient ([P, 1, 3]).  If it is the tensor the most recent rasterizer backward returned (not a copy, nothing
+    accumulated into another buffer), the 3 floats behind it are spare: returns the [P + 1, 3] tensor over both (the sh_rank1
+    exchange writes the camera centre into the last row instead of concatenating 12 B per Gaussian), else None."""
+    if _last_dc_grad is None or g is None or not g.is_contiguous() or (g.data_ptr(), g.numel()) != _last_dc_grad:
+        return None
+    return torch.empty(0, dtype=g.dtype, device=g.device).set_(g.untyped_storage(), g.storage_offset(), (g.numel() // 3 + 1, 3), (3, 1))
+
+
 def skip_sh_rest_grad_in_next_backward(on=True):
     """One-shot (view-sharded exchange "sh_rank1", scene_utils/parallel.py): the next rasterizer backward of a call that got `dc`
     and `shs` separately forms dL/ddc only and returns None for `shs` - the ranks exchange dL/ddc and rebuild the other
@@ -364,7 +394,19 @@ class _RasterizeGaussians(torch.autograd.Function):
                 fused = _fused_adam_struct(_fused_optimizer, (means3D, dc, sh, opacities, scales, rotations),
                                            rows="with_instances" if split else None)
             d_means2D = torch.empty(P, 3, dtype=torch.float32, device=dev)
-            if fused is None:
+            if fused is None and P > 0:
+                # ONE allocation for the gradients, geometry first: a data-parallel caller can exchange the four geometry tensors
+                # (and dc + rest) as one contiguous span - one collective instead of four (scene_utils.parallel.GradBucket) - and
+                # the dc gradient is followed by a spare row for the camera centre of the sh_rank1 exchange (dc_grad_tail_row)
+                d_means3D, d_opac, d_scales, d_rot, d_dc, d_sh, d_col, d_cov = _grad_arena(dev, (
+                    ((P, 3), 0), (tuple(opacities.shape) if opacities is not None else (P, 1), 0),
+                    ((P, 3) if scales is not None else None, 0), ((P, 4) if rotations is not None else None, 0),
+                    (tuple(dc.shape) if dc is not None else None, 3),
+                    (tuple(sh.shape) if sh is not None and not skip_rest else None, 0),
+                    ((P, 3) if colors_precomp is not None else None, 0), ((P, 6) if cov3D_precomp is not None else None, 0)))
+                global _last_dc_grad
+                _last_dc_grad = (d_dc.data_ptr(), d_dc.numel()) if d_dc is not None else None
+            elif fused is None:
                 d_means3D = torch.empty(P, 3, dtype=torch.float32, device=dev)
                 d_opac = torch.empty(opacities.shape if opacities is not None else (P, 1), dtype=torch.float32, device=dev)
                 d_dc = like(dc, *(dc.shape if dc is not None else ()))

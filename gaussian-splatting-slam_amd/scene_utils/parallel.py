@@ -44,6 +44,37 @@ def _nothing_to_exchange(world: int) -> bool:
     return world <= 1 and not (dist.is_available() and dist.is_initialized())
 
 
+def adjacent_spans(tensors, max_gap=256):
+    """Contiguous tensors that lie in ONE storage with gaps of at most `max_gap` elements between them (the rasterizer's
+    backward returns its gradients that way: diff_gaussian_rasterization._grad_arena), grouped into flat 1-D tensors over
+    [first start, last end): one collective per span instead of one per tensor.  -> [(flat, [tensors of the span])]; a tensor
+    that shares nothing is its own span (flat = its own flattened view).  (The gaps travel too: alignment padding, never read.)
+    The ORDER of the spans depends only on the order of `tensors` and on their offsets inside a storage - never on addresses -
+    so every rank issues its collectives in the same order."""
+    groups = {}                                    # storage -> indices, in order of first appearance
+    for i, t in enumerate(tensors):
+        groups.setdefault(t.untyped_storage().data_ptr(), []).append(i)
+    out = []
+    for idx in groups.values():
+        idx.sort(key=lambda i: tensors[i].storage_offset())
+        run = [tensors[idx[0]]]
+        for i in idx[1:] + [None]:
+            t = tensors[i] if i is not None else None
+            end = run[-1].storage_offset() + run[-1].numel()
+            if t is not None and t.dtype == run[0].dtype and 0 <= t.storage_offset() - end <= max_gap:
+                run.append(t)
+                continue
+            if len(run) == 1:
+                out.append((run[0].view(-1), run))
+            else:
+                start = run[0].storage_offset()
+                flat = torch.empty(0, dtype=run[0].dtype, device=run[0].device).set_(run[0].untyped_storage(), start,
+                                                                                     (end - start,), (1,))
+                out.append((flat, run))
+            run = [t]
+    return out
+
+
 class GradBucket:
     """Sums the gradients of `params` over ranks and leaves the MEAN in `.grad`.
 
@@ -65,20 +96,20 @@ class GradBucket:
         backend = dist.get_backend(group)
         use_avg = backend == "nccl"                  # RCCL averages in the reduction; gloo has no AVG
         todo = self.params if params is None else list(params)
-        works = []
         for p in todo:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-            g = p.grad
-            if not g.is_contiguous():
-                g = p.grad = g.contiguous()
-            works.append(dist.all_reduce(g, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, group=group,
-                                         async_op=True))
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+        # gradients that sit side by side in one allocation (the rasterizer's backward returns them so) go as ONE collective
+        spans = adjacent_spans([p.grad for p in todo])
+        works = [dist.all_reduce(flat, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, group=group, async_op=True)
+                 for flat, _ in spans]
         for w in works:
             w.wait()
         if not use_avg:
-            for p in todo:
-                p.grad.mul_(1.0 / world)
+            for flat, _ in spans:
+                flat.mul_(1.0 / world)
 
 
     def all_reduce_visible_rows(self, world: int, visible, group=None, params=None):
@@ -158,7 +189,14 @@ def rank1_sh_exchange(xyz, f_dc, f_rest, cam_center, sh_degree: int, world: int,
     P = int(xyz.shape[0])
     krest = int(f_rest.shape[1]) if f_rest.numel() else 0
     g = f_dc.grad if f_dc.grad is not None else torch.zeros_like(f_dc)
-    mine = torch.cat((g.reshape(P, 3), cam_center.reshape(1, 3).to(g)), dim=0).contiguous()        # [P + 1, 3]
+    mine = None
+    if g.is_cuda:
+        from diff_gaussian_rasterization import dc_grad_tail_row
+        mine = dc_grad_tail_row(g)                   # the backward left a spare row behind its dc gradient: no concatenation
+        if mine is not None:
+            mine[P].copy_(cam_center.reshape(3).to(g))
+    if mine is None:
+        mine = torch.cat((g.reshape(P, 3), cam_center.reshape(1, 3).to(g)), dim=0).contiguous()    # [P + 1, 3]
     gathered = torch.empty(world * (P + 1), 3, dtype=g.dtype, device=g.device)
     dist.all_gather_into_tensor(gathered, mine, group=group)
     if g.is_cuda and optimizer is not None:

@@ -297,3 +297,72 @@ def _worker_odd(rank, world, port, out_dir):
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_adjacent_spans_grouping_is_address_independent():
+    """Gradients returned side by side in one allocation travel as one collective; the grouping (and the order in which spans
+    come out = the order collectives are issued in) depends on list order and offsets only, never on addresses."""
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-slam_amd"))
+    from scene_utils.parallel import adjacent_spans
+    from diff_gaussian_rasterization import _grad_arena, GRAD_ARENA_ALIGN
+    P = 1001
+    xyz, op, sc, rot, dc, rest, col, cov = _grad_arena("cpu", (((P, 3), 0), ((P, 1), 0), ((P, 3), 0), ((P, 4), 0), ((P, 1, 3), 3),
+                                                               ((P, 15, 3), 0), (None, 0), (None, 0)))
+    assert col is None and cov is None
+    for t in (xyz, op, sc, rot, dc, rest):
+        assert t.is_contiguous() and t.storage_offset() % GRAD_ARENA_ALIGN == 0
+    assert dc.storage_offset() + dc.numel() + 3 <= rest.storage_offset()        # the spare row behind dc
+    lone = torch.zeros(7)
+    spans = adjacent_spans([lone, xyz, op, sc, rot])
+    assert [len(m) for _, m in spans] == [1, 4] and spans[1][1][0] is xyz and spans[1][0].numel() == rot.storage_offset() + rot.numel()
+    # param order of the model (xyz, f_dc, f_rest, opacity, scaling, rotation): still one span, members by offset
+    flat, members = adjacent_spans([xyz, dc, rest, op, sc, rot])[0]
+    assert [m.data_ptr() for m in members] == [t.data_ptr() for t in (xyz, op, sc, rot, dc, rest)]
+    for i, t in enumerate((xyz, op, sc, rot, dc, rest)):
+        t.fill_(float(i + 1))
+    flat.mul_(2.0)
+    assert all(bool((t == 2.0 * (i + 1)).all()) for i, t in enumerate((xyz, op, sc, rot, dc, rest)))
+    # a hole larger than the tolerated gap splits the span: geometry without opacity ... rotation
+    assert [len(m) for _, m in adjacent_spans([xyz, rot])] == [1, 1]
+    # different storages keep list order
+    a, b = torch.zeros(4), torch.zeros(3)
+    assert [f.numel() for f, _ in adjacent_spans([a, b])] == [4, 3] and [f.numel() for f, _ in adjacent_spans([b, a])] == [3, 4]
+
+
+def test_all_reduce_mean_of_arena_gradients_two_ranks(tmp_path):
+    """GradBucket.all_reduce_mean with the gradients in one arena (one collective over the span) gives the per-tensor mean."""
+    port = 35000 + (os.getpid() % 2000)
+    mp.spawn(_worker_arena, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(2))
+    for x, y, m in zip(a["got"], b["got"], a["expect"]):
+        assert torch.equal(x, y) and torch.equal(x, m)
+    assert a["spans"] == b["spans"] == 1
+
+
+def _worker_arena(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from scene_utils import init_from_env, GradBucket
+    from scene_utils.parallel import adjacent_spans
+    from diff_gaussian_rasterization import _grad_arena
+    init_from_env("gloo")
+    P = 333
+    shapes = ((P, 3), (P, 1), (P, 3), (P, 4))
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    per_rank = []
+    for r in range(world):
+        gen = torch.Generator().manual_seed(50 + r)
+        per_rank.append([torch.randn(s, generator=gen) for s in shapes])
+    grads = _grad_arena("cpu", tuple((s, 0) for s in shapes))
+    for p, g, src in zip(params, grads, per_rank[rank]):
+        g.copy_(src)
+        p.grad = g
+    n_spans = len(adjacent_spans([p.grad for p in params]))
+    GradBucket(params).all_reduce_mean(world)
+    expect = [(a + b) * (1.0 / world) for a, b in zip(*per_rank)]
+    torch.save(dict(got=[p.grad.clone() for p in params], expect=expect, spans=n_spans), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
