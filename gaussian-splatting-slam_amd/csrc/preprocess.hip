@@ -581,7 +581,8 @@ __global__ __launch_bounds__(BT) void k_shade(int P, int deg, int sh_stride, con
 // K8 + K9 backward, fused with the per-Gaussian gather of per-instance gradients.
 // One thread per Gaussian index (all per-Gaussian arrays coalesced).
 // igrad record (render backward): (S_x, S_y, S_xx, S_xy) (S_yy, d_opacity_eff, d_r, d_g) (d_b, d_invdepth, -, -) with
-// S_* = sums over the instance's pixels of g, g dx, ... (g = dL/dpower, d = mean - pixel).  With
+// S_* = opacity_eff x the record's sums over the instance's pixels of h dx, h dx^2 ... (h = dL/dpower / opacity_eff, d = mean -
+// pixel; the multiplication happens here, once per Gaussian).  With
 // power = -0.5(A dx^2 + C dy^2) - B dx dy:  dL/dA = -S_xx/2, dL/dB = -S_xy, dL/dC = -S_yy/2 and
 // dL/dmean2D(ndc) = (W/2)(-A S_x - B S_y), (H/2)(-C S_y - B S_x): linear in the sums, so applied once, after the gather.
 // ---------------------------------------------------------------------------------------------------
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
       acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
       acc[8] += r2.x; acc[9] += r2.y;
     }
-    const float gA = -0.5f * acc[2], gB = -acc[3], gC = -0.5f * acc[4], g_op_eff = acc[5];
+    const float g_op_eff = acc[5];
     float g_rgb[3] = {acc[6], acc[7], acc[8]};
     const float g_invd = acc[9];
 
@@ -782,6 +783,14 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
     ewa_project(t, v, cov6, fx, fy, tanfovx, tanfovy, e);
     const float a = e.a0 + 0.3f, c = e.c0 + 0.3f, b = e.b;
     const float det = a * c - b * b;
+    const float opac = load_opacity(opacities, (size_t)idx, raw_act);
+    {
+      // the records hold the moments of h = dL/dpower / opacity_eff (render.hip): the factor, as the forward formed it
+      const float op_eff = antialiasing ? opac * sqrtf(fmaxf(0.000025f, (e.a0 * e.c0 - b * b) / det)) : opac;
+#pragma unroll
+      for (int i = 0; i < 5; i++) acc[i] *= op_eff;
+    }
+    const float gA = -0.5f * acc[2], gB = -acc[3], gC = -0.5f * acc[4];
     {
       // conic exactly as the forward computed it (a visible Gaussian has det != 0)
       const float det_inv = 1.0f / det;
@@ -793,7 +802,6 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
     float g_a = det2inv * (-c * c * gA + b * c * gB - b * b * gC);
     float g_c = det2inv * (-b * b * gA + a * b * gB - a * a * gC);
     float g_b = det2inv * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
-    const float opac = load_opacity(opacities, (size_t)idx, raw_act);
     if (antialiasing) {
       const float det0 = e.a0 * e.c0 - b * b;
       const float f = det0 / det;

@@ -14,9 +14,9 @@
 // private LDS slab, the block adds the four slabs in a fixed order and writes one 48-B gradient record per
 // (tile, instance) at the instance's emission slot.  The per-Gaussian sum over instances happens in k_preprocess_bwd
 // (deterministic).
-// Record = (sum g dx, sum g dy, sum g dx^2, sum g dx dy) (sum g dy^2, dL/dopacity_eff, d_r, d_g) (d_b, d_invdepth, -, -)
-// with g = dL/dpower and d = mean - pixel: raw moments; k_preprocess_bwd turns their per-Gaussian totals into
-// dL/dmean2D and dL/dconic.
+// Record = (sum h dx, sum h dy, sum h dx^2, sum h dx dy) (sum h dy^2, sum h = dL/dopacity_eff, d_r, d_g) (d_b, d_invdepth, -, -)
+// with h = dL/dpower / opacity_eff (the per-pixel dL/dopacity_eff) and d = mean - pixel: raw moments; k_preprocess_bwd turns
+// their per-Gaussian totals, times opacity_eff, into dL/dmean2D and dL/dconic.
 #include <stdlib.h>
 #include <string.h>
 
@@ -380,13 +380,12 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       S = __builtin_fmaf(a_e, diff, S);
       const float dL_dalpha = diff * T + neg_Tf_bg * rcp;
       const float v6 = dch * gp0, v7 = dch * gp1, v8 = dch * gp2, v9 = DEPTH ? dch * gd : 0.f;
-      // Geometry: only the raw moments of g = dL/dpower = G alpha-gradient are reduced here; the per-Gaussian linear map
-      // to (dL/dmean2D, dL/dconic) uses wave-uniform factors (conic, W/2, H/2) and is applied once per Gaussian AFTER the
-      // sum over its instances, in k_preprocess_bwd.
-      const float v5 = G_e * dL_dalpha;                               // -> dL/dopacity
-      const float g = bb.y * v5;
-      const float v0 = g * dx, v1 = g * dy;                           // sum g dx, sum g dy
-      const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;           // sum g dx^2, g dx dy, g dy^2
+      // Geometry: only the raw moments of v5 = dL/dpower / opacity_eff are reduced here; the per-Gaussian linear map to
+      // (dL/dmean2D, dL/dconic) uses wave-uniform factors (opacity_eff, conic, W/2, H/2) and is applied once per Gaussian AFTER
+      // the sum over its instances, in k_preprocess_bwd.
+      const float v5 = G_e * dL_dalpha;                               // -> dL/dopacity_eff; g = opacity_eff v5 = dL/dpower
+      const float v0 = v5 * dx, v1 = v5 * dy;                         // sum v5 dx, sum v5 dy   (the factor opacity_eff: k_preprocess_bwd)
+      const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;           // sum v5 dx^2, v5 dx dy, v5 dy^2
       float u0, u1;
       if (DEPTH) wave_sum10_halving(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, lane_bit3, u0, u1);
       else wave_sum9_halving(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane_bit3, u0, u1);
@@ -528,7 +527,6 @@ __global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x
     const int n = min(BWD1_BATCH, toDo - b * BWD1_BATCH);
     float4 a = s0v[0], bb = s1v[0];
     for (int j = 0; j < n; j++) {
-      const float4 an = s0v[j + 1], bn = s1v[j + 1];   // next entry's record, in flight while this one is processed
       const int entry1 = toDo - (b * BWD1_BATCH + j);  // 1-based list position of this entry
       bool any = false;                                // (wave-uniform)
       const float dx0 = a.x - px0, dy0 = a.y - py0;
@@ -558,9 +556,10 @@ __global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x
         const float diff = cg - S[s];
         S[s] = __builtin_fmaf(a_e, diff, S[s]);
         const float dL_dalpha = diff * T[s] + nTb[s] * rcp;
+        // v5 = this pixel's dL/dopacity_eff; the geometry moments are taken of v5, not of g = opacity_eff v5 = dL/dpower: the
+        // factor is wave-uniform and is applied once per Gaussian, after the sum over its instances (k_preprocess_bwd)
         const float v5 = G_e * dL_dalpha;
-        const float g = bb.y * v5;
-        const float t0 = g * dx, t1 = g * dy;
+        const float t0 = v5 * dx, t1 = v5 * dy;
         acc0 += t0;
         acc1 += t1;
         acc2 = __builtin_fmaf(t0, dx, acc2);
@@ -572,6 +571,12 @@ __global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x
         acc8 = __builtin_fmaf(dch, gp2[s], acc8);
         if (DEPTH) acc9 = __builtin_fmaf(dch, gd[s], acc9);
       }
+      // The next entry's record is requested HERE, behind the last use of this one and into the same registers (a rotating
+      // pair of register sets cost four v_mov_b64 per entry); the reduction below, or the other waves, cover the LDS latency.
+      __builtin_amdgcn_sched_barrier(0);
+      a = s0v[j + 1];
+      bb = s1v[j + 1];
+      __builtin_amdgcn_sched_barrier(0);
       if (any) {
         float u0, u1;
         if (DEPTH) wave_sum10_halving(acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7, acc8, acc9, lane_bit3, u0, u1);
@@ -582,8 +587,6 @@ __global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x
         acc0 = acc1 = acc2 = acc3 = acc4 = acc5 = acc6 = acc7 = acc8 = 0.f;
         if (DEPTH) acc9 = 0.f;
       }
-      a = an;
-      bb = bn;
     }
     __syncthreads();
     // flush the batch: 3 float4 per entry, at the entry's emission slot (grouped per Gaussian for k_preprocess_bwd)
