@@ -292,9 +292,11 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   int rc;
   char* geom = (char*)geometry_state;
   uint32_t* meta = (uint32_t*)(geom + L.meta);
-  // meta (num_rendered, flags) and, right behind it, the depth sort's digit histograms + pass tickets
+  // meta (num_rendered, flags) and, right behind it, the depth sort's digit histograms + pass tickets: cleared here for the
+  // global-order form.  The tile-local form has no depth sort and its scan kernel writes every meta word itself
+  // (k_scan_block_sums): no memset launch in front of the projection
   static_assert(sizeof(uint32_t) == 4, "");
-  if ((rc = gsr_check(hipMemsetAsync(meta, 0, 256 + GSR_RADIX_HEAD_WORDS * 4, st), "memset meta"))) return rc;
+  if (!tile_local && (rc = gsr_check(hipMemsetAsync(meta, 0, 256 + GSR_RADIX_HEAD_WORDS * 4, st), "memset meta"))) return rc;
 
   gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, /*block_sums=*/tile_local, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;

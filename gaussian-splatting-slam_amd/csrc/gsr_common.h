@@ -8,6 +8,7 @@
 #include "../../include/gsr.h"
 
 #define GSR_TILE 16                 // 16x16 pixel tiles
+#define GSR_BLOCK_CULLED 0x80000000u  // top bit of a projection workgroup's instance total (tile-local form): a prefiltered point of it was culled
 #define GSR_TILE_PIX 256
 #define GSR_WAVE 64
 #define GSR_REC_F4 3                // packed splat record = 3 float4 = 48 B

@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
   int32_t out_radius = 0;                       // defaults for a culled Gaussian
   uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu;
   bool on_screen = false;                       // passed the near plane, det != 0, non-empty 3-sigma rectangle
+  bool culled_flag = false;                     // prefiltered = true and this Gaussian fails the near-plane test
   float px = 0.f, py = 0.f, sA = 0.f, sB = 0.f, sC = 0.f, op = 0.f, spmin = 0.f, depth = 1.f;
   int cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;
   float p[3] = {0.f, 0.f, 0.f};
@@ -375,7 +376,10 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
         }
       }
     } else if (prefiltered) {
-      meta[1] = 1u;  // prefiltered point failed the near-plane test (hard error upstream)
+      // prefiltered point failed the near-plane test (hard error upstream).  Tile-local form: the flag rides in the top bit of
+      // this workgroup's instance total (below), so nothing has to be cleared before this kernel starts
+      if (block_sums) culled_flag = true;
+      else meta[1] = 1u;
     }
   }
 
@@ -440,28 +444,37 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
     if ((threadIdx.x & 63) == 0) tile_sum[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = (tile_sum[0] + tile_sum[1]) + (tile_sum[2] + tile_sum[3]);
+    const int any_culled = __syncthreads_or(culled_flag ? 1 : 0);
+    // (a workgroup's 256 Gaussians reach < 2^31 tiles: bit 31 is free for the "prefiltered point culled" flag)
+    if (threadIdx.x == 0)
+      block_sums[blockIdx.x] = ((tile_sum[0] + tile_sum[1]) + (tile_sum[2] + tile_sum[3])) | (any_culled ? GSR_BLOCK_CULLED : 0u);
   }
 }
 
 // Start slot of every projection workgroup's instances (exclusive prefix sum of block_sums) and num_rendered (64-bit, into
 // meta[2..3]) - ONE workgroup; 3907 sums at 1 M Gaussians.
 // `early` (optional): the device-side alias of a pinned host word; the count goes there as ONE 8-byte store, tagged valid and
-// carrying the "prefiltered point culled" flag of meta[1] (final since the projection kernel), for a host that waits for the
+// carrying the "prefiltered point culled" flag, for a host that waits for the
 // count while the rest of the frame is still queued (api.hip, wait_for_count).
-__global__ __launch_bounds__(1024) void k_scan_block_sums(int nb, const uint32_t* __restrict__ block_sums,
-                                                         uint32_t* __restrict__ block_offs,
-                                                         unsigned long long* __restrict__ total,
-                                                         const uint32_t* __restrict__ flags,
+// The kernel also (re)writes the eight status words of `meta` - [0] 0, [1] "prefiltered point culled" (OR of the flag bits the
+// projection workgroups left in the top bit of their totals, which are stored back WITHOUT it for k_emit_instances), [2..3]
+// num_rendered, [4] longest tile list so far = 0, [5..7] 0 - so the tile-local forward needs no memset in front of it.
+__global__ __launch_bounds__(1024) void k_scan_block_sums(int nb, uint32_t* __restrict__ block_sums,
+                                                         uint32_t* __restrict__ block_offs, uint32_t* __restrict__ meta,
                                                          unsigned long long* __restrict__ early) {
   __shared__ unsigned long long wsum[16];
   __shared__ unsigned long long carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   unsigned long long carry = 0ull;
+  int culled = 0;
   for (int base = 0; base < nb; base += 1024) {
     const int i = base + tid;
-    const uint32_t v = i < nb ? block_sums[i] : 0u;
+    uint32_t v = i < nb ? block_sums[i] : 0u;
+    if (v & GSR_BLOCK_CULLED) {
+      culled = 1;
+      v &= ~GSR_BLOCK_CULLED;
+      block_sums[i] = v;
+    }
     unsigned long long inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -477,10 +490,15 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(int nb, const uint32_t
     __syncthreads();
     carry = carry_s;
   }
+  culled = __syncthreads_or(culled);
   if (tid == 0) {
-    *total = carry;
+    meta[0] = 0u;
+    meta[1] = culled ? 1u : 0u;
+    meta[2] = (uint32_t)carry;
+    meta[3] = (uint32_t)(carry >> 32);
+    meta[4] = meta[5] = meta[6] = meta[7] = 0u;
     if (early)
-      __hip_atomic_store(early, (1ull << 63) | ((unsigned long long)(flags[0] & 1u) << 62) | (carry & ((1ull << 62) - 1ull)),
+      __hip_atomic_store(early, (1ull << 63) | ((unsigned long long)(culled ? 1u : 0u) << 62) | (carry & ((1ull << 62) - 1ull)),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -488,9 +506,8 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(int nb, const uint32_t
 void gsr_launch_scan_block_sums(int P, char* geom, const GsrGeomLayout& L, uint32_t* meta, unsigned long long* early,
                                 hipStream_t st) {
   const int nb = (P + 255) / 256;
-  GSR_LAUNCH("scan_block_sums", k_scan_block_sums, dim3(1), dim3(1024), 0, st, nb, (const uint32_t*)(geom + L.offsets),
-             (uint32_t*)(geom + L.offsets) + nb, reinterpret_cast<unsigned long long*>(meta + 2),
-             (const uint32_t*)(meta + 1), early);
+  GSR_LAUNCH("scan_block_sums", k_scan_block_sums, dim3(1), dim3(1024), 0, st, nb, (uint32_t*)(geom + L.offsets),
+             (uint32_t*)(geom + L.offsets) + nb, meta, early);
 }
 
 // num_rendered = sum of tiles_touched does not depend on the depth order: summed right after the projection (integer
