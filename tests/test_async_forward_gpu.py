@@ -380,6 +380,57 @@ def test_lowlevel_verified_overflow_then_rerender_matches_blocking_state(tlo):
     _check_state(lib, a, big, cap, W, H, color, invd, radii)
 
 
+@pytest.mark.parametrize("tlo", [0, 1])
+def test_lowlevel_forward_ignores_state_contents_and_reports_prefiltered_culls(tlo):
+    """The three state buffers are opaque scratch: a forward into buffers full of 0xFF leaves the blocking path's results (the
+    tile-local form runs no memset at all: its scan kernel writes every status word).  And `prefiltered` with a point behind the
+    near plane is the published hard error in both forms - returned by the verified call, flagged in the status words of the
+    unverified one (tile-local form: the flag travels in the projection workgroups' instance totals)."""
+    from diff_gaussian_rasterization import _C, _stream, _settings_struct, _gauss_struct
+    P, W, H = 4000, 176, 112
+    a, lib, s, g, keep = _lowlevel_setup(P, W, H)
+    dev = "cuda"
+    cap = int(a["R"] * 1.5) + 1000
+
+    def buffers():
+        geom = torch.full((lib.gsr_geometry_state_bytes(P),), 0xFF, dtype=torch.uint8, device=dev)
+        img = torch.full((lib.gsr_image_state_bytes(W, H),), 0xFF, dtype=torch.uint8, device=dev)
+        binning = torch.full((lib.gsr_binning_state_bytes(P, W, H, cap),), 0xFF, dtype=torch.uint8, device=dev)
+        radii = torch.full((P,), -1, dtype=torch.int32, device=dev)
+        return geom, img, binning, radii, torch.empty(3, H, W, device=dev), torch.empty(1, H, W, device=dev)
+
+    def call(s_, g_, bufs, verify):
+        geom, img, binning, radii, color, invd = bufs
+        status = torch.full((4,), -1, dtype=torch.int64).pin_memory()
+        count = C.c_int64(-1)
+        rc = lib.gsr_forward_async(C.byref(s_), C.byref(g_), _C.ptr(geom), geom.numel(), _C.ptr(radii), _C.ptr(binning),
+                                   binning.numel(), cap, _C.ptr(img), img.numel(), _C.ptr(color), _C.ptr(invd), 1, 0, None,
+                                   C.c_void_p(status.data_ptr()), tlo, _stream(), C.byref(count) if verify else None)
+        torch.cuda.synchronize()
+        return rc, count.value, status
+
+    for verify in (True, False):
+        bufs = buffers()
+        rc, n, status = call(s, g, bufs, verify)
+        assert rc == 0 and int(status[1]) == a["R"] and (not verify or n == a["R"])
+        assert (int(status[0]) >> 32) & 1 == 0                      # no cull flag
+        _check_state(lib, a, bufs[2], cap, W, H, bufs[4], bufs[5], bufs[3])
+    # one Gaussian moved into the camera centre: behind the near plane
+    _, t, inp, rs = keep
+    means = t["means3D"].clone()
+    means[P // 2] = rs.campos.to(means)
+    s2, keep2 = _settings_struct(rs._replace(prefiltered=True), dev)
+    g2 = _gauss_struct(P, means, None, t["shs"], None, t["opacities"], t["scales"], t["rotations"], None)
+    rc, n, status = call(s2, g2, buffers(), True)
+    assert rc != 0 and "filtered" in _C.last_error()
+    rc, n, status = call(s2, g2, buffers(), False)
+    assert rc == 0 and (int(status[0]) >> 32) & 1 == 1
+    # and the same scene without `prefiltered` is simply rendered
+    s3, keep3 = _settings_struct(rs, dev)
+    rc, n, status = call(s3, g2, buffers(), True)
+    assert rc == 0 and (int(status[0]) >> 32) & 1 == 0 and n > 0
+
+
 def test_parity_suite_with_the_other_backward_form_and_other_forward_modes():
     """The two forms of the compositing backward (one wave per tile from 6000 tiles up, four waves per tile below) are chosen by
     image size, so the small-image parity tests only ever see the four-wave form.  Re-run the core parity tests in a child
