@@ -332,7 +332,9 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
     if (host_status && !early &&
         (rc = gsr_check(hipMemcpyAsync(host_status, meta, 16, hipMemcpyDeviceToHost, st), "read num_rendered")))
       return rc;
-    if (copied && (rc = gsr_check(hipEventRecord(copied, st), "record read-back event"))) return rc;
+    // (the event only marks the copy: with the early word the host watches pinned memory instead, and an event record is not
+    // free on the stream - ~6 us between the scan and the emission)
+    if (copied && !early && (rc = gsr_check(hipEventRecord(copied, st), "record read-back event"))) return rc;
     return debug_sync(s, st, "tile-count scan");
   }
   gsr_launch_sum_tiles(P, geom, L, meta, st);

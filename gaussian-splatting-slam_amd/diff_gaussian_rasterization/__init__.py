@@ -295,9 +295,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                     R = pool.capacity_for_frame(key)
                     binning = ws.ensure_binning(lib, P, W, H, R)
                     status = pool.status_slot()
-                    status[2] = 0
+                    status[2] = _ws.STATUS_PENDING     # (overwritten by the compositing kernel when the frame's status arrives)
                     tlo = 1 if _ws.tile_local_binning(pool, key) else 0
                     count = C.c_int64(-1)
+                    rerendered = False
                     verify = mode == "exact" or key not in pool.capacity     # ("async": a shape's first frame is verified too -
                     #                                                           its capacity is a guess, not an observation)
                     _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
@@ -313,6 +314,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                             # the frame just enqueued was composited from a truncated list: same frame again, phase 2 only, on a
                             # binning state that holds it (stream-ordered behind the first attempt, which stays inside its buffers)
                             pool.stats["rerendered_frames"] += 1
+                            rerendered = True
                             R = _ws._capacity_for(n)
                             binning = ws.ensure_binning(lib, P, W, H, R)
                             _C.check(lib.gsr_forward_rerender(C.byref(s), C.byref(g), _C.ptr(geom), _C.ptr(binning),
@@ -321,8 +323,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                               C.c_void_p(status.data_ptr()), stream))
                         pool.note(key, n)
                     pool.stats["exact_frames" if mode == "exact" else "async_frames"] += 1
-                    done = torch.cuda.Event()
-                    done.record()
+                    # a verified frame's status (only its longest tile list is still of interest) is recognised by the
+                    # sentinel above being overwritten: no event on the stream (a record costs ~6 us of device time between the
+                    # compositing kernel and the loss); an unverified frame's is waited for in order, behind an event
+                    done = None
+                    if not verify or rerendered:       # (a re-rendered frame writes its status twice: wait for the last one)
+                        done = torch.cuda.Event()
+                        done.record()
                     pool.pending.append((done, status, R, key, pool.ticket, verify))
                 else:
                     # blocking read-back of num_rendered (the published rasterizer's one host synchronisation): debug mode,

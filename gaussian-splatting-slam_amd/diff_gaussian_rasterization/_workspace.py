@@ -110,6 +110,18 @@ class Lease:
 
 
 WAIT_LIMIT_S = float(os.environ.get("GSR_COUNT_TIMEOUT_S", "120"))
+STATUS_PENDING = -1          # third status word (longest tile list | 0) before the device has written the frame's status
+
+
+class _StatusArrived:
+    """Event-like view of a pinned status slot: "done" once the device has overwritten the sentinel in its third word (the low
+    half: an aligned 4-byte store, never seen torn)."""
+
+    def __init__(self, status):
+        self.status = status
+
+    def query(self):
+        return (int(self.status[2]) & 0xFFFFFFFF) != 0xFFFFFFFF
 
 
 def _wait_bounded(ev, what):
@@ -191,6 +203,8 @@ class Pool:
         """Looks at the statuses of earlier speculative forwards that have completed (all of them with wait=True)."""
         while self.pending:
             ev, status, cap, key, ticket, verified = self.pending[0]
+            if ev is None:
+                ev = _StatusArrived(status)
             if wait:
                 _wait_bounded(ev, f"the status of frame {ticket}")
             elif not ev.query():

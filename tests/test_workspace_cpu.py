@@ -96,3 +96,23 @@ def test_long_lists_send_a_shape_back_to_the_global_binning_form():
     assert p.longest_list[key] == 5000 and not ws.tile_local_binning(p, key)
     p.forget_estimates()
     assert ws.tile_local_binning(p, key) and not p.capacity
+
+
+def test_verified_frames_need_no_event_the_status_sentinel_tells():
+    """A verified frame is queued without an event: its status counts as arrived once the device has overwritten the sentinel in
+    the low half of the third word (the longest tile list); frames behind a pending one wait their turn."""
+    ws, p = _pool()
+    key = (9000, 96, 64)
+    p.capacity[key] = 16384
+    a, b = p.status_slot(), p.status_slot()
+    a[2] = b[2] = ws.STATUS_PENDING
+    p.pending.append((None, a, 16384, key, 1, True))
+    p.pending.append((None, b, 16384, key, 2, True))
+    p.poll()
+    assert len(p.pending) == 2 and key not in p.longest_list
+    b[1], b[2] = 4000, 3000                      # the later frame's status is there, the earlier one's is not: order is kept
+    p.poll()
+    assert len(p.pending) == 2
+    a[1], a[2] = 4000, -(1 << 32) + 1200          # high half still the sentinel's (0xFFFFFFFF): only the low half counts
+    p.poll()
+    assert not p.pending and p.longest_list[key] == 3000 and len(p.status_free) == 2
