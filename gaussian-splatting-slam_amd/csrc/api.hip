@@ -16,14 +16,14 @@
 // launchers defined in the kernel files
 void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool,
                                bool, hipStream_t);
-void gsr_launch_scan_block_sums(int, char*, const GsrGeomLayout&, uint32_t*, unsigned long long*, hipStream_t);
 void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, bool, hipStream_t);
 void gsr_launch_adam_culled_rows(int, int, const char*, const GsrGeomLayout&, const GsrAdamArgs&, uint32_t, hipStream_t);
 int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
                               const GsrGeomLayout&, const float4*, uint32_t, const gsr_grads*, const GsrAdamArgs*, int,
                               hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
-void gsr_launch_emit(int, int, int, const char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, bool, hipStream_t);
+void gsr_launch_emit(int, int, int, char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, bool, unsigned long long*,
+                     hipStream_t);
 void gsr_launch_tile_depth_sort(int, bool, const uint2*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*,
                                 uint32_t*, hipStream_t);
 void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
@@ -282,7 +282,8 @@ static uint32_t* device_alias_of_pinned(uint32_t* host) {
 static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
                             int32_t* radii, hipStream_t st, bool defer_color, uint32_t* host_status,
                             hipEvent_t copied /* recorded right behind the status copy, or nullptr */,
-                            SideShade* shade_aside = nullptr, bool tile_local = false, bool* early_word = nullptr) {
+                            SideShade* shade_aside = nullptr, bool tile_local = false,
+                            unsigned long long** early_word = nullptr) {
   const int P = g->P;
   const GsrGeomLayout L = gsr_geom_layout(P);
   if (!geometry_state || geometry_bytes < L.total) {
@@ -293,8 +294,8 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   char* geom = (char*)geometry_state;
   uint32_t* meta = (uint32_t*)(geom + L.meta);
   // meta (num_rendered, flags) and, right behind it, the depth sort's digit histograms + pass tickets: cleared here for the
-  // global-order form.  The tile-local form has no depth sort and its scan kernel writes every meta word itself
-  // (k_scan_block_sums): no memset launch in front of the projection
+  // global-order form.  The tile-local form has no depth sort and its emission kernel writes every meta word itself
+  // (k_emit_instances): no memset launch in front of the projection
   static_assert(sizeof(uint32_t) == 4, "");
   if (!tile_local && (rc = gsr_check(hipMemsetAsync(meta, 0, 256 + GSR_RADIX_HEAD_WORDS * 4, st), "memset meta"))) return rc;
 
@@ -315,10 +316,10 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   // non-blocking caller looks at them whenever it likes.
   if (tile_local) {
     // second form of the binning stage (binning.hip, k_tile_depth_sort): no global depth order; the instances are emitted in
-    // index order, so the projection kernel has left per-workgroup instance totals: one single-workgroup scan gives the start
-    // slots and num_rendered, and k_emit_instances finishes the prefix sum itself
-    // (a caller that waits for the count - forward_prepare_impl, gsr_forward_async(num_rendered_out) - gets it from the scan
-    // kernel itself: one 8-byte store into this thread's pinned slot, word pair [8..9], GSR_COUNT_VALID | flag << 62 | count)
+    // index order, the projection kernel has left per-workgroup instance totals and k_emit_instances (forward_render_impl)
+    // takes the prefix sum and num_rendered from them itself.  A caller that waits for the count - gsr_forward_async(
+    // num_rendered_out) - gets it from that kernel: one 8-byte store into this thread's pinned slot, word pair [8..9],
+    // GSR_COUNT_VALID | flag << 62 | count; here only the slot is armed.
     unsigned long long* early = nullptr;
     if (host_status) {
       DeviceLocal* d = device_local();
@@ -327,15 +328,8 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
         early = (unsigned long long*)(d->pinned_dev + 8);
       }
     }
-    if (early_word) *early_word = early != nullptr;
-    gsr_launch_scan_block_sums(P, geom, L, meta, early, st);
-    if (host_status && !early &&
-        (rc = gsr_check(hipMemcpyAsync(host_status, meta, 16, hipMemcpyDeviceToHost, st), "read num_rendered")))
-      return rc;
-    // (the event only marks the copy: with the early word the host watches pinned memory instead, and an event record is not
-    // free on the stream - ~6 us between the scan and the emission)
-    if (copied && !early && (rc = gsr_check(hipEventRecord(copied, st), "record read-back event"))) return rc;
-    return debug_sync(s, st, "tile-count scan");
+    if (early_word) *early_word = early;
+    return debug_sync(s, st, "projection");
   }
   gsr_launch_sum_tiles(P, geom, L, meta, st);
   if (host_status &&
@@ -425,10 +419,9 @@ static int64_t forward_prepare_impl(const gsr_settings* s, const gsr_gaussians* 
   if (!host || !ev) { gsr_set_error("hipHostMalloc / hipEventCreate failed"); return GSR_ERR_HIP; }
   // the host waits on an event recorded right behind the 16-byte copy, i.e. while the depth sort and the offset scan are still
   // queued: the GPU has ~0.1 ms of work left when the host goes on to size the binning state and enqueue the rest
-  bool early = false;
-  if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, st, defer_color, host, ev, nullptr, false, &early)))
+  if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, st, defer_color, host, ev, nullptr, false, nullptr)))
     return rc;
-  return wait_for_count(host, ev, early);
+  return wait_for_count(host, ev, false);
 }
 
 int64_t gsr_forward_prepare(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state,
@@ -457,7 +450,8 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
                                size_t binning_bytes, int64_t num_rendered, void* image_state, size_t image_bytes,
                                float* out_color, float* out_invdepth, bool for_backward, bool shade_late,
                                hipEvent_t sh_ready, void* stream, bool tile_local = false,
-                               uint32_t* host_status_late = nullptr) {
+                               uint32_t* host_status_late = nullptr, unsigned long long* early = nullptr,
+                               uint32_t* host_count = nullptr, hipEvent_t count_copied = nullptr) {
   int rc = validate(s, g);
   if (rc) return rc;
   if (num_rendered < 0 || num_rendered > 0x3FFFFFFFll) {   // the tile sort counts keys in 30-bit fields (sort_scan.hip)
@@ -484,7 +478,13 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   if (R == 0 || g->P == 0) {   // nothing to emit: every tile range is empty (otherwise the emit kernel clears them on its way)
     if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
   } else {
-    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, st);
+    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, early, st);
+    // tile-local form: the emission kernel is where num_rendered comes into being.  A waiting caller whose pinned slot has no
+    // device alias (early == nullptr) gets the status words by a copy, marked by an event
+    if (tile_local && host_count && !early) {
+      if ((rc = gsr_check(hipMemcpyAsync(host_count, geom + GL.meta, 16, hipMemcpyDeviceToHost, st), "read num_rendered"))) return rc;
+      if (count_copied && (rc = gsr_check(hipEventRecord(count_copied, st), "record read-back event"))) return rc;
+    }
     {
       SideShade* a = (tile_local && !shade_late && sh_ready) ? side_shade() : nullptr;
       if (a && sh_ready == a->join) {      // colour pass on the side stream, beside the tile sort (see forward_geometry)
@@ -585,7 +585,7 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
     // binning and compositing stages queued, so it never idles while the host looks
     uint32_t* host = nullptr;
     hipEvent_t ev = nullptr;
-    bool early = false;
+    unsigned long long* early = nullptr;
     if (num_rendered_out) {
       host = pinned_slot();
       ev = readback_event();
@@ -597,10 +597,11 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
     // (the caller's status words - flags, num_rendered and, in the tile-local form, the longest tile list meta[4] - leave at the END)
     rc = forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
                              out_color, out_invdepth, for_backward != 0, aside ? false : late,
-                             aside ? aside->join : (hipEvent_t)sh_ready_event, stream, tlo, host_status);
+                             aside ? aside->join : (hipEvent_t)sh_ready_event, stream, tlo, host_status, early, tlo ? host : nullptr,
+                             ev);
     if (rc) return rc;
     if (num_rendered_out) {
-      const int64_t n = wait_for_count(host, ev, early);
+      const int64_t n = wait_for_count(host, ev, early != nullptr);
       if (n < 0) return (int)n;
       *num_rendered_out = n;
     }

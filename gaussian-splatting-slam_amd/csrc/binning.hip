@@ -18,9 +18,12 @@
 #define EMIT_WINDOW 4096
 #endif
 //
-// order == nullptr (tile-local binning form): emission in index order; offsets_incl then holds, per projection workgroup
-// (= per workgroup here), the instance total [b] and the start slot [nb + b] (k_scan_block_sums), and the scan is finished
-// here from tiles_touched.
+// order == nullptr (tile-local binning form): emission in index order; offsets_incl then holds the instance total of every
+// projection workgroup (= workgroup here; bit 31 = "a prefiltered point of it was culled") and the WHOLE prefix sum happens
+// here: a workgroup adds up the totals in front of its own (<= P / 256 words, L2-resident) and finishes the scan from
+// tiles_touched; workgroup 0 also adds up all of them and leaves the frame's status words in `meta` ([1] cull flag, [2..3]
+// num_rendered, the rest 0) and, for a host that waits for the count, in the pinned word `early` (api.hip wait_for_count).
+// One launch less than a scan kernel in between, and nothing in the geometry state has to be cleared beforehand.
 __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ offsets_incl,
                                                         const uint32_t* __restrict__ tiles_touched,
@@ -29,9 +32,11 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
                                                         uint32_t* __restrict__ gauss_of_slot,
                                                         uint32_t* __restrict__ slot_start, int tiles,
                                                         uint2* __restrict__ ranges, uint32_t cap,
-                                                        uint32_t* __restrict__ sort_head) {
+                                                        uint32_t* __restrict__ sort_head, uint32_t* __restrict__ meta,
+                                                        unsigned long long* __restrict__ early) {
   __shared__ uint32_t lkey[EMIT_WINDOW], lgid[EMIT_WINDOW];
   __shared__ uint32_t wave_tot[4];
+  __shared__ unsigned long long wave_pre[4];
   // the tile sort that follows wants its digit histograms and pass tickets zeroed (sort_scan.hip, head_zeroed)
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < GSR_RADIX_HEAD_WORDS; i += 256) sort_head[i] = 0u;
@@ -50,8 +55,44 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
     }
   } else {
     const int nb = (P + 255) / 256;
-    count = offsets_incl[blockIdx.x];
-    slot0 = offsets_incl[nb + blockIdx.x];
+    count = offsets_incl[blockIdx.x] & ~GSR_BLOCK_CULLED;
+    {
+      // instances of the workgroups in front of this one (workgroup 0: of all of them = num_rendered, and the cull flags)
+      const int upto = blockIdx.x == 0 ? nb : (int)blockIdx.x;
+      unsigned long long part = 0ull;
+      uint32_t flag = 0u;
+      // (16-byte loads, all of a thread's in flight together: <= 4 per thread at 1 M Gaussians; the array is 256-B aligned)
+      const uint4* v4 = reinterpret_cast<const uint4*>(offsets_incl);
+      const int upto4 = upto >> 2;
+#pragma unroll 4
+      for (int i = threadIdx.x; i < upto4; i += 256) {
+        const uint4 q = v4[i];
+        part += (unsigned long long)(q.x & ~GSR_BLOCK_CULLED) + (q.y & ~GSR_BLOCK_CULLED) + (q.z & ~GSR_BLOCK_CULLED) +
+                (q.w & ~GSR_BLOCK_CULLED);
+        flag |= (q.x | q.y) | (q.z | q.w);
+      }
+      if ((int)threadIdx.x < (upto & 3)) {
+        const uint32_t v = offsets_incl[4 * upto4 + threadIdx.x];
+        part += v & ~GSR_BLOCK_CULLED;
+        flag |= v;
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+      if ((threadIdx.x & 63) == 0) wave_pre[threadIdx.x >> 6] = part;
+      const int culled = __syncthreads_or((int)(flag >> 31));
+      const unsigned long long sum = (wave_pre[0] + wave_pre[1]) + (wave_pre[2] + wave_pre[3]);
+      slot0 = blockIdx.x == 0 ? 0u : (uint32_t)sum;     // (a count beyond 2^30 is refused by the caller: 32 bits suffice)
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        meta[0] = 0u;
+        meta[1] = culled ? 1u : 0u;
+        meta[2] = (uint32_t)sum;
+        meta[3] = (uint32_t)(sum >> 32);
+        meta[4] = meta[5] = meta[6] = meta[7] = 0u;
+        if (early)
+          __hip_atomic_store(early, (1ull << 63) | ((unsigned long long)(culled ? 1u : 0u) << 62) | (sum & ((1ull << 62) - 1ull)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     n = j < P ? tiles_touched[j] : 0u;
     uint32_t inc = n;
 #pragma unroll
@@ -351,13 +392,14 @@ void gsr_launch_tile_depth_sort(int tiles, bool dual, const uint2* ranges, uint3
 #endif
 }
 
-void gsr_launch_emit(int P, int grid_x, int tiles, const char* geom, const GsrGeomLayout& GL, char* bin,
-                     const GsrBinLayout& BL, uint32_t cap, bool index_order, hipStream_t st) {
+void gsr_launch_emit(int P, int grid_x, int tiles, char* geom, const GsrGeomLayout& GL, char* bin,
+                     const GsrBinLayout& BL, uint32_t cap, bool index_order, unsigned long long* early, hipStream_t st) {
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
              index_order ? (const uint32_t*)nullptr : (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
              (const uint32_t*)(geom + GL.tiles_touched),
              (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
-             (uint32_t*)(geom + GL.slot_start), tiles, (uint2*)(bin + BL.ranges), cap, (uint32_t*)(bin + BL.radix_tmp));
+             (uint32_t*)(geom + GL.slot_start), tiles, (uint2*)(bin + BL.ranges), cap, (uint32_t*)(bin + BL.radix_tmp),
+             (uint32_t*)(geom + GL.meta), index_order ? early : (unsigned long long*)nullptr);
 }
 
 void gsr_launch_finalize(uint32_t cap, const uint32_t* n_dev, const uint32_t* tile_sorted, char* bin,

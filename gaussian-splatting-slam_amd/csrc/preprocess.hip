@@ -437,8 +437,8 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     depth_key[idx] = out_key;   // `order` is not written: the depth sort takes value = index on its first pass
   }
   // tile-local binning form: instances are emitted in index order, so the prefix sum of the tile counts is taken over the
-  // workgroups of THIS kernel: each leaves its total, k_scan_block_sums turns the totals into start slots (and num_rendered),
-  // and k_emit_instances finishes the scan inside its workgroup - one small launch instead of four
+  // workgroups of THIS kernel: each leaves its total, and k_emit_instances does the rest (start slot of its workgroup from the
+  // totals in front of it, the scan inside the workgroup, num_rendered) - no scan launch at all
   if (block_sums) {                                                    // (kernel argument: uniform)
     uint32_t acc = out_tiles;
 #pragma unroll
@@ -449,65 +449,6 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     if (threadIdx.x == 0)
       block_sums[blockIdx.x] = ((tile_sum[0] + tile_sum[1]) + (tile_sum[2] + tile_sum[3])) | (any_culled ? GSR_BLOCK_CULLED : 0u);
   }
-}
-
-// Start slot of every projection workgroup's instances (exclusive prefix sum of block_sums) and num_rendered (64-bit, into
-// meta[2..3]) - ONE workgroup; 3907 sums at 1 M Gaussians.
-// `early` (optional): the device-side alias of a pinned host word; the count goes there as ONE 8-byte store, tagged valid and
-// carrying the "prefiltered point culled" flag, for a host that waits for the
-// count while the rest of the frame is still queued (api.hip, wait_for_count).
-// The kernel also (re)writes the eight status words of `meta` - [0] 0, [1] "prefiltered point culled" (OR of the flag bits the
-// projection workgroups left in the top bit of their totals, which are stored back WITHOUT it for k_emit_instances), [2..3]
-// num_rendered, [4] longest tile list so far = 0, [5..7] 0 - so the tile-local forward needs no memset in front of it.
-__global__ __launch_bounds__(1024) void k_scan_block_sums(int nb, uint32_t* __restrict__ block_sums,
-                                                         uint32_t* __restrict__ block_offs, uint32_t* __restrict__ meta,
-                                                         unsigned long long* __restrict__ early) {
-  __shared__ unsigned long long wsum[16];
-  __shared__ unsigned long long carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  unsigned long long carry = 0ull;
-  int culled = 0;
-  for (int base = 0; base < nb; base += 1024) {
-    const int i = base + tid;
-    uint32_t v = i < nb ? block_sums[i] : 0u;
-    if (v & GSR_BLOCK_CULLED) {
-      culled = 1;
-      v &= ~GSR_BLOCK_CULLED;
-      block_sums[i] = v;
-    }
-    unsigned long long inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long t = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += t;
-    }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    unsigned long long pre = carry;
-    for (int k = 0; k < w; k++) pre += wsum[k];
-    if (i < nb) block_offs[i] = (uint32_t)(pre + inc - v);   // (a count beyond 2^30 is refused by the caller: 32 bits suffice)
-    if (tid == 1023) carry_s = pre + inc;
-    __syncthreads();
-    carry = carry_s;
-  }
-  culled = __syncthreads_or(culled);
-  if (tid == 0) {
-    meta[0] = 0u;
-    meta[1] = culled ? 1u : 0u;
-    meta[2] = (uint32_t)carry;
-    meta[3] = (uint32_t)(carry >> 32);
-    meta[4] = meta[5] = meta[6] = meta[7] = 0u;
-    if (early)
-      __hip_atomic_store(early, (1ull << 63) | ((unsigned long long)(culled ? 1u : 0u) << 62) | (carry & ((1ull << 62) - 1ull)),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-void gsr_launch_scan_block_sums(int P, char* geom, const GsrGeomLayout& L, uint32_t* meta, unsigned long long* early,
-                                hipStream_t st) {
-  const int nb = (P + 255) / 256;
-  GSR_LAUNCH("scan_block_sums", k_scan_block_sums, dim3(1), dim3(1024), 0, st, nb, (uint32_t*)(geom + L.offsets),
-             (uint32_t*)(geom + L.offsets) + nb, meta, early);
 }
 
 // num_rendered = sum of tiles_touched does not depend on the depth order: summed right after the projection (integer
