@@ -372,4 +372,88 @@ int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* i
   return gsr_launch_status("ssim backward launch");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// weight * mean |(a - b) mask| and its gradient w.r.t. a: the inverse-depth regularisation term of a training step, reference
+// train.py:124-132 (`torch.abs((invDepth - mono_invdepth) * depth_mask).mean()`; mask optional) - in torch ~12 element-wise /
+// reduction launches forward + backward, 0.13 ms at 4K.
+// Forward: per-workgroup partial sums (fixed order inside a workgroup), then one workgroup adds them in index order:
+// deterministic.  Backward: upstream[0] * weight * sign((a - b) mask) mask / n (sign(0) = 0 like torch).
+// ---------------------------------------------------------------------------------------------------------------
+#define L1_BLOCKS 1024
+__global__ __launch_bounds__(256) void k_l1_partial(const float* __restrict__ a, const float* __restrict__ b,
+                                                    const float* __restrict__ mask, long long n, float* __restrict__ partials) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  const long long n4 = n >> 2;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  const float4* m4 = reinterpret_cast<const float4*>(mask);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 x = a4[i], y = b4[i];
+    const float4 m = mask ? m4[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+    acc += (fabsf((x.x - y.x) * m.x) + fabsf((x.y - y.y) * m.y)) + (fabsf((x.z - y.z) * m.z) + fabsf((x.w - y.w) * m.w));
+  }
+  if (blockIdx.x == 0 && (long long)threadIdx.x < (n & 3)) {
+    const long long i = 4 * n4 + threadIdx.x;
+    acc += fabsf((a[i] - b[i]) * (mask ? mask[i] : 1.f));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(L1_BLOCKS) void k_l1_finalize(const float* __restrict__ partials, int nblk, float scale,
+                                                           float* __restrict__ out) {
+  __shared__ float red[L1_BLOCKS];
+  red[threadIdx.x] = (int)threadIdx.x < nblk ? partials[threadIdx.x] : 0.f;
+  __syncthreads();
+  for (int sft = L1_BLOCKS / 2; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+__global__ __launch_bounds__(256) void k_l1_bwd(const float* __restrict__ a, const float* __restrict__ b,
+                                                const float* __restrict__ mask, long long n, const float* __restrict__ upstream,
+                                                float scale, float* __restrict__ grad) {
+  const float g = (upstream ? upstream[0] : 1.0f) * scale;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float m = mask ? mask[i] : 1.f;
+    const float d = (a[i] - b[i]) * m;
+    grad[i] = d > 0.f ? g * m : (d < 0.f ? -g * m : 0.f);
+  }
+}
+
+// partials: L1_BLOCKS floats of scratch (gsr_l1_mean_blocks()); a, b, mask 16-byte aligned; mask may be NULL
+int32_t gsr_l1_mean_blocks(void) { return L1_BLOCKS; }
+
+int gsr_l1_mean_forward(int64_t n, float weight, const float* a, const float* b, const float* mask, float* partials, float* out,
+                        void* stream) {
+  if (n <= 0 || !a || !b || !partials || !out || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)mask) & 15)) {
+    gsr_set_error("l1_mean_forward: bad arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)min((long long)L1_BLOCKS, (long long)((n / 4 + 255) / 256 > 0 ? (n / 4 + 255) / 256 : 1));
+  GSR_LAUNCH("l1_partial", k_l1_partial, dim3(nblk), dim3(256), 0, st, a, b, mask, (long long)n, partials);
+  GSR_LAUNCH("l1_finalize", k_l1_finalize, dim3(1), dim3(L1_BLOCKS), 0, st, (const float*)partials, nblk, weight / (float)n, out);
+  return gsr_launch_status("l1 mean forward launch");
+}
+
+int gsr_l1_mean_backward(int64_t n, float weight, const float* a, const float* b, const float* mask, const float* upstream,
+                         float* grad, void* stream) {
+  if (n <= 0 || !a || !b || !grad) {
+    gsr_set_error("l1_mean_backward: bad arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  const int nblk = (int)min((long long)4096, (long long)((n + 255) / 256));
+  GSR_LAUNCH("l1_bwd", k_l1_bwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, b, mask, (long long)n, upstream, weight / (float)n, grad);
+  return gsr_launch_status("l1 mean backward launch");
+}
+
 }  // extern "C"

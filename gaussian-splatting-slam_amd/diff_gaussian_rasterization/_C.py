@@ -101,6 +101,9 @@ EXPORTS = {
     "gsr_fused_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),
     "gsr_fused_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
     "gsr_fused_loss_blocks": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gsr_l1_mean_blocks": (C.c_int32, []),
+    "gsr_l1_mean_forward": (C.c_int, [C.c_int64, C.c_float] + [C.c_void_p] * 6),
+    "gsr_l1_mean_backward": (C.c_int, [C.c_int64, C.c_float] + [C.c_void_p] * 6),
     "gsr_fused_l1_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float] +
                                   [C.c_void_p] * 8),
     "gsr_fused_l1_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float] + [C.c_void_p] * 8),

@@ -76,3 +76,42 @@ class _FusedL1SSIMLoss(torch.autograd.Function):
 
 def fused_l1_ssim_loss(img1, img2, lambda_dssim=0.2):
     return _FusedL1SSIMLoss.apply(img1, img2, lambda_dssim)
+
+
+class _L1Mean(torch.autograd.Function):
+    """weight * mean|(a - b) mask|, gradient to `a`: the inverse-depth term of reference train.py:124-132 in three HIP launches."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, mask):
+        if not a.is_cuda:
+            raise _C.GsrError("l1_mean_loss needs tensors on the HIP device (no CPU path)")
+        lib = _C.lib()
+        x = a.detach().float().contiguous()
+        y = b.detach().float().contiguous()
+        m = mask.detach().float().expand_as(x).contiguous() if mask is not None else None
+        if x.shape != y.shape:
+            raise ValueError("l1_mean_loss: shapes differ")
+        partials = torch.empty(int(lib.gsr_l1_mean_blocks()), dtype=torch.float32, device=x.device)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        with _C.on_device(x.device):
+            _C.check(lib.gsr_l1_mean_forward(x.numel(), float(weight), _C.ptr(x), _C.ptr(y), _C.ptr(m) if m is not None else None,
+                                             _C.ptr(partials), _C.ptr(out), _C._stream()))
+        ctx.save_for_backward(x, y, *([m] if m is not None else []))
+        ctx.weight = float(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.lib()
+        x, y, *m = ctx.saved_tensors
+        g = g.detach().float().contiguous()
+        grad = torch.empty_like(x)
+        with _C.on_device(x.device):
+            _C.check(lib.gsr_l1_mean_backward(x.numel(), ctx.weight, _C.ptr(x), _C.ptr(y), _C.ptr(m[0]) if m else None, _C.ptr(g),
+                                              _C.ptr(grad), _C._stream()))
+        return grad, None, None, None
+
+
+def l1_mean_loss(a, b, weight=1.0, mask=None):
+    """`weight * torch.abs((a - b) * mask).mean()` (reference train.py:130-131), gradient to `a`."""
+    return _L1Mean.apply(a, b, weight, mask)

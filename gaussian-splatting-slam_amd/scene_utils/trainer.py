@@ -50,6 +50,7 @@ class Trainer:
         if not callable(loss) and loss != "hip":
             raise ValueError("loss: 'hip' or a callable (the pure-PyTorch loss is test infrastructure: oracle/loss_oracle.py)")
         self.loss_fn = loss if callable(loss) else training_loss_fused
+        self._loss_arg = loss
         self.bucket = GradBucket(model.parameters()) if self.distributed else None
         # N > 1 gradient exchange: "allreduce" (one all-reduce per leaf, every rank runs the whole update),
         # "visible_rows" (the same, restricted to the rows some rank saw), "sharded" (reduce-scatter -> Adam on a 1/N row shard
@@ -132,7 +133,11 @@ class Trainer:
             vis = _LazyVisibility(pkg)       # `radii > 0`: only materialised by the branches that use it
             loss = self.loss_fn(image, self.gt_images[v], self.lambda_dssim)
             if self.depth_weight > 0 and self.depth_targets is not None:
-                loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[v]).mean()
+                if pkg["depth"].is_cuda and not callable(self._loss_arg):
+                    from fused_ssim import l1_mean_loss
+                    loss = loss + l1_mean_loss(pkg["depth"], self.depth_targets[v], self.depth_weight)
+                else:
+                    loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[v]).mean()
             if len(views) > 1:
                 loss = loss / len(views)
             # this view's densification statistics ride in the rasterizer's backward (one pass and one launch less); any

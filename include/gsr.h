@@ -294,6 +294,16 @@ int gsr_fused_l1_ssim_backward(int32_t planes, int32_t H, int32_t W, float lambd
                                const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                                float* dL_dimg1, void* stream);
 
+/* weight * mean|(a - b) mask| over n floats and its gradient w.r.t. a: the inverse-depth regularisation term of a training
+ * step (reference train.py:124-132, `Ll1depth`; `mask` = depth_mask, may be NULL), three launches instead of torch's dozen.
+ * a, b, mask 16-byte aligned; partials: gsr_l1_mean_blocks() floats of scratch; out / upstream: DEVICE scalars (upstream NULL
+ * = 1).  Deterministic. */
+int32_t gsr_l1_mean_blocks(void);
+int gsr_l1_mean_forward(int64_t n, float weight, const float* a, const float* b, const float* mask, float* partials, float* out,
+                        void* stream);
+int gsr_l1_mean_backward(int64_t n, float weight, const float* a, const float* b, const float* mask, const float* upstream,
+                         float* grad, void* stream);
+
 /* One-launch Adam over up to 8 tensors.  Dense = torch.optim.Adam semantics (reference scene/gaussian_model.py:169-170
  * default optimizer); sparse = `SparseGaussianAdam.step(visibility, N)` (reference train.py:37-41,173-176): rows of
  * invisible Gaussians untouched, no bias correction.  Array arguments are HOST arrays of `count` entries; betas / eps are

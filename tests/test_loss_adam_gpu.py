@@ -195,3 +195,31 @@ def test_split_dense_adam_culled_rows_on_side_stream_is_bit_identical():
     for a, b in zip(out[False], out[True]):
         for x, y in zip(a, b):
             assert torch.equal(x, y), float((x - y).abs().max())
+
+
+@pytest.mark.parametrize("shape,masked", [((1, 67, 45), False), ((1, 270, 481), True), ((1, 2160, 3840), True)])
+def test_l1_mean_loss_matches_torch(shape, masked):
+    """fused_ssim.l1_mean_loss (the inverse-depth term of reference train.py:124-132) against the torch expression it replaces,
+    value and gradient (float64 on the CPU), non-unit upstream gradient, exact ties, bitwise reproducible."""
+    from fused_ssim import l1_mean_loss
+    gen = torch.Generator().manual_seed(sum(shape))
+    a = torch.rand(*shape, generator=gen, dtype=torch.float64)
+    b = a + 0.05 * torch.randn(*shape, generator=gen, dtype=torch.float64)
+    b[:, :3, :5] = a[:, :3, :5]                               # exact ties: sign(0) = 0 like torch
+    mask = (torch.rand(*shape, generator=gen) > 0.3).double() if masked else None
+    a_ref = a.clone().requires_grad_(True)
+    ref = 0.7 * torch.abs((a_ref - b) * (mask if masked else 1.0)).mean()
+    (2.5 * ref).backward()
+    runs = []
+    for _ in range(2):
+        a_gpu = a.float().cuda().requires_grad_(True)
+        val = l1_mean_loss(a_gpu, b.float().cuda(), 0.7, mask.float().cuda() if masked else None)
+        (2.5 * val).backward()
+        runs.append((val.item(), a_gpu.grad.clone()))
+    assert abs(runs[0][0] - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    g, g_ref = runs[0][1].cpu().double(), a_ref.grad
+    # fp32 rounding of a and b can flip the sign of a difference that is ~1e-8: compare away from ties
+    far = (a - b).abs() > 1e-6
+    assert torch.allclose(g[far], g_ref[far], rtol=1e-5, atol=1e-12)
+    assert bool((g[:, :3, :5] == 0).all())
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
