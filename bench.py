@@ -412,7 +412,8 @@ def main():
     trainer.finish()       # ... and here, so the timed region holds exactly K complete optimizer steps
     barrier()
     elapsed = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_seq = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = sorted(step_seq)
     host_ms.sort()
 
     def pct(v, q):
@@ -425,6 +426,7 @@ def main():
 
     log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step; Gaussians now {model.get_xyz.shape[0]}")
     result = {
+        **({"step_ms_sequence": [round(x, 4) for x in step_seq]} if os.environ.get("BENCH_DUMP_STEPS") == "1" else {}),
         "metric": "train_iters_per_sec", "value": round(world * k * args.steps / elapsed, 3),
         "unit": "view-iterations/s (render fwd + L1/DSSIM loss + bwd + Adam)", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
