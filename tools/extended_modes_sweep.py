@@ -19,14 +19,33 @@ from diff_gaussian_rasterization import _workspace as ws  # noqa: E402
 from helpers import run_hip, upstream_grads  # noqa: E402
 from test_sweep_gpu import _case  # noqa: E402
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-bad, rerendered, t0 = [], 0, time.time()
+LONG = "--long" in sys.argv          # many Gaussians on a small image: tile lists of 1 000 - 9 000 entries (the per-tile ordering's
+args = [a for a in sys.argv[1:] if a != "--long"]   # second launch, <= 4096, and its in-memory path beyond the LDS capacity)
+first = int(args[0]) if len(args) > 0 else 0
+count = int(args[1]) if len(args) > 1 else 200
+
+
+def _long_case(seed):
+    import math
+    from scene_utils import make_gaussians, look_at_camera
+    g = torch.Generator().manual_seed(8000 + seed)
+
+    def u(a, b):
+        return a + (b - a) * float(torch.rand((), generator=g))
+    P, W, H, deg = int(u(1500, 9000)), int(u(17, 70)), int(u(17, 60)), seed % 4
+    raw = make_gaussians(P, deg, seed=8100 + seed, scale_factor=u(0.5, 3.0))
+    raw.opacity += u(-4.0, 0.0)               # mostly faint: the lists stay long instead of saturating early
+    th, ph = u(0, 2 * math.pi), u(-1.0, 1.0)
+    eye = (4.0 * math.cos(th) * math.cos(ph), 4.0 * math.sin(th) * math.cos(ph), 4.0 * math.sin(ph))
+    cam = look_at_camera(eye, (0.0, 0.0, 0.0), (0, 0, 1), u(0.5, 0.9), W, H)
+    return raw, cam, deg, ("sh", "dc", "colors")[(seed // 4) % 3], bool(seed % 2), torch.rand(3, generator=g), 1.0
+
+bad, rerendered, longest, t0 = [], 0, 0, time.time()
 old_mode, old_bin, old_min = ws.forward_mode(), ws._BINNING, ws.MIN_CAPACITY
 ws.MIN_CAPACITY = 256                       # (small scenes: let the first-frame guess be wrong sometimes)
 try:
     for seed in range(first, first + count):
-        raw, cam, deg, mode, aa, bg, sm = _case(seed)
+        raw, cam, deg, mode, aa, bg, sm = _long_case(seed) if LONG else _case(seed)
         gc, gd = upstream_grads(cam.image_height, cam.image_width, seed=seed)
         outs = []
         try:
@@ -38,6 +57,8 @@ try:
                 before = pool.stats["rerendered_frames"]
                 outs.append(run_hip(raw, cam, deg, bg, mode=mode, antialiasing=aa, scale_modifier=sm, gc=gc, gd=gd))
                 rerendered += pool.stats["rerendered_frames"] - before
+                pool.poll(wait=True)
+                longest = max([longest] + list(pool.longest_list.values()))
             a = outs[0]
             for b in outs[1:]:
                 for k in ("color", "radii", "invdepth"):
@@ -48,7 +69,8 @@ try:
             bad.append(seed)
             print(f"seed {seed}: {type(e).__name__}: {str(e)[:300]}", flush=True)
         if (seed - first) % 50 == 49:
-            print(f"... {seed - first + 1} cases, {len(bad)} failures, {rerendered} re-rendered frames, {time.time() - t0:.0f} s", flush=True)
+            print(f"... {seed - first + 1} cases, {len(bad)} failures, {rerendered} re-rendered frames, longest tile list so far "
+                  f"{longest}, {time.time() - t0:.0f} s", flush=True)
 finally:
     dgr.set_forward_mode(old_mode)
     ws._BINNING, ws.MIN_CAPACITY = old_bin, old_min
