@@ -287,6 +287,9 @@ def main():
                          "priority, so the small binning kernels are dispatched ahead of the bandwidth-bound SH update)")
     ap.add_argument("--split-rows", action="store_true",
                     help="hip_fused: update the rows without tile instances on a side stream beside the compositing backward")
+    ap.add_argument("--graph", action="store_true",
+                    help="N=1: the training step as ONE HIP graph launch (Trainer.enable_graph_replay: captured once per model "
+                         "size, replayed; same results bit for bit).  Pays where the step is launch-bound (configs 1, 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--forward-mode", default=None, choices=["exact", "async", "sync"],
@@ -367,6 +370,10 @@ def main():
                       overlap_comm=False if args.no_overlap else (True if args.overlap else None),
                       exchange=args.exchange, single_rank_group=single_rank_group)
     trainer.split_rows = bool(args.split_rows)
+    if args.graph:
+        if world > 1 or single_rank_group:
+            raise SystemExit("--graph: one rank only")
+        trainer.enable_graph_replay()
     if args.densify:
         # cameras_extent of the reference = 1.1 x radius of the camera centres (scene/dataset_readers.py getNerfppNorm)
         trainer.enable_densification(extent=1.1 * 4.0, from_iter=args.densify_from,
@@ -427,6 +434,7 @@ def main():
     log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step; Gaussians now {model.get_xyz.shape[0]}")
     result = {
         **({"step_ms_sequence": [round(x, 4) for x in step_seq]} if os.environ.get("BENCH_DUMP_STEPS") == "1" else {}),
+        **({"graph_replay": dict(trainer.graph_stats)} if args.graph else {}),
         "metric": "train_iters_per_sec", "value": round(world * k * args.steps / elapsed, 3),
         "unit": "view-iterations/s (render fwd + L1/DSSIM loss + bwd + Adam)", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -641,7 +641,38 @@ static int adam_args(const gsr_gaussians* g, const gsr_fused_adam* opt, GsrAdamA
   A.beta1 = (float)opt->beta1; A.beta2 = (float)opt->beta2;
   A.omb1 = (float)(1.0 - opt->beta1); A.omb2 = (float)(1.0 - opt->beta2);
   A.eps = (float)opt->eps;
+  A.dyn = opt->dynamic;
   return 0;
+}
+
+__global__ void k_adam_set_dynamic(GsrAdamArgs A, float* __restrict__ dyn) {
+  const int i = threadIdx.x;
+  if (i < 6) {
+    dyn[i] = A.lr[i];
+    dyn[6 + i] = A.step_size[i];
+    dyn[12 + i] = A.inv_bc2_sqrt[i];
+  }
+}
+
+extern "C" int gsr_adam_set_dynamic(const gsr_fused_adam* opt, float* dynamic_dev, void* stream) {
+  if (!opt || !dynamic_dev) {
+    gsr_set_error("adam_set_dynamic: bad arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  // (the same arithmetic as adam_args: lr / (1 - beta1^step) and 1 / sqrt(1 - beta2^step) formed in double)
+  GsrAdamArgs A;
+  for (int i = 0; i < 6; i++) {
+    A.p[i] = A.m[i] = A.v[i] = nullptr;
+    A.lr[i] = opt->lr[i];
+    const double bc1 = 1.0 - pow(opt->beta1, (double)opt->step[i]);
+    const double bc2 = 1.0 - pow(opt->beta2, (double)opt->step[i]);
+    A.step_size[i] = opt->sparse == 1 ? 0.f : (float)((double)opt->lr[i] / bc1);
+    A.inv_bc2_sqrt[i] = opt->sparse == 1 ? 0.f : (float)(1.0 / sqrt(bc2));
+  }
+  A.beta1 = A.beta2 = A.omb1 = A.omb2 = A.eps = 0.f;
+  A.dyn = nullptr;
+  hipLaunchKernelGGL(k_adam_set_dynamic, dim3(1), dim3(64), 0, (hipStream_t)stream, A, dynamic_dev);
+  return gsr_launch_status("adam set dynamic");
 }
 
 static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,

@@ -166,7 +166,23 @@ struct GsrAdamArgs {
   float* v[6];
   float lr[6], step_size[6], inv_bc2_sqrt[6];
   float beta1, beta2, omb1, omb2, eps;
+  const float* dyn;   // optional device copy of (lr, step_size, inv_bc2_sqrt) that overrides the three arrays above (HIP-graph replay)
 };
+
+// the per-step factors as the kernel should use them: from the launch arguments, or from device memory when the caller keeps
+// them there (gsr_fused_adam.dynamic).  Wave-uniform loads of 18 floats.
+__device__ __forceinline__ GsrAdamArgs gsr_adam_resolve(const GsrAdamArgs& in) {
+  GsrAdamArgs A = in;
+  if (in.dyn) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      A.lr[i] = in.dyn[i];
+      A.step_size[i] = in.dyn[6 + i];
+      A.inv_bc2_sqrt[i] = in.dyn[12 + i];
+    }
+  }
+  return A;
+}
 
 // -------------------------------------------------------------------------------------------------
 // host-side launch helpers (api.hip owns the definitions)

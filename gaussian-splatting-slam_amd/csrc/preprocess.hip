@@ -591,8 +591,9 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
     float* __restrict__ dL_ddc, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dcov3D, float* __restrict__ st_accum, float* __restrict__ st_denom,
-    float* __restrict__ st_max_radii, const GsrAdamArgs A) {
+    float* __restrict__ st_max_radii, const GsrAdamArgs A_in) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+  const GsrAdamArgs A = ADAM ? gsr_adam_resolve(A_in) : A_in;
   __shared__ int32_t need_sh[BT];
   const int S = 3 * sh_stride, Sp = S | 1;
   const size_t row0 = (size_t)blockIdx.x * BT;
@@ -1091,8 +1092,9 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
 // another stream WHILE the compositing kernels (VALU-bound, little HBM traffic) run; k_preprocess_bwd<., 3> then updates the
 // rows with instances.  Same adam_elem as everywhere: the two kernels together equal k_preprocess_bwd<., 1> bit for bit.
 __global__ __launch_bounds__(256) void k_adam_culled_rows(int P, int sh_stride, const uint32_t* __restrict__ tiles_touched,
-                                                          const GsrAdamArgs A, const uint32_t* __restrict__ n_dev,
+                                                          const GsrAdamArgs A_in, const uint32_t* __restrict__ n_dev,
                                                           uint32_t cap) {
+  const GsrAdamArgs A = gsr_adam_resolve(A_in);
   __shared__ int32_t culled[256];
   if (gsr_overflowed(n_dev, cap)) return;   // the other half of the update (k_preprocess_bwd<., 3>) skips the frame too
   const size_t row0 = (size_t)blockIdx.x * 256;

@@ -50,6 +50,7 @@ class gsr_fused_adam(C.Structure):
     _fields_ = [
         ("exp_avg", C.c_void_p * 6), ("exp_avg_sq", C.c_void_p * 6), ("lr", C.c_float * 6), ("step", C.c_int64 * 6),
         ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("sparse", C.c_int32),
+        ("dynamic", C.c_void_p),
     ]
 
 
@@ -101,6 +102,7 @@ EXPORTS = {
     "gsr_fused_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),
     "gsr_fused_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
     "gsr_fused_loss_blocks": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gsr_adam_set_dynamic": (C.c_int, [C.POINTER(gsr_fused_adam), C.c_void_p, C.c_void_p]),
     "gsr_l1_mean_blocks": (C.c_int32, []),
     "gsr_l1_mean_forward": (C.c_int, [C.c_int64, C.c_float] + [C.c_void_p] * 6),
     "gsr_l1_mean_backward": (C.c_int, [C.c_int64, C.c_float] + [C.c_void_p] * 6),
@@ -130,7 +132,8 @@ EXPORTS = {
     "gsr_profile_read": (C.c_int32, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }
 
-ABI_VERSION = 4      # GSR_ABI_VERSION of include/gsr.h
+ADAM_DYNAMIC_FLOATS = 18     # GSR_ADAM_DYNAMIC_FLOATS
+ABI_VERSION = 5      # GSR_ABI_VERSION of include/gsr.h
 _lib = None
 
 

@@ -169,7 +169,50 @@ def _fused_adam_struct(opt, tensors, advance=True, rows=None):
     b1, b2 = (0.9, 0.999) if sparse else g0["betas"]
     fa.beta1, fa.beta2, fa.eps = float(b1), float(b2), float(g0["eps"])
     fa.sparse = 1 if sparse else (2 if rows == "with_instances" else 0)
+    dyn = getattr(opt, "_gsr_dynamic", None)
+    fa.dynamic = dyn.data_ptr() if dyn is not None else None
     return fa, keep
+
+
+def enable_dynamic_hyperparameters(opt):
+    """Keeps the per-step factors of `opt`'s folded update (lr, lr / bias_correction1, 1 / sqrt(bias_correction2) per group) in
+    device memory (gsr_fused_adam.dynamic): the backward's launch arguments then hold nothing that changes from step to step, so a
+    training step can be captured ONCE into a HIP graph and replayed, with `push_dynamic_hyperparameters` in front of each replay.
+    Eager backwards keep working (they push the step's values themselves); same results bit for bit."""
+    if getattr(opt, "_gsr_dynamic", None) is None:
+        p0 = opt.param_groups[0]["params"][0]
+        opt._gsr_dynamic = torch.zeros(_C.ADAM_DYNAMIC_FLOATS, dtype=torch.float32, device=p0.device)
+    return opt._gsr_dynamic
+
+
+def push_dynamic_hyperparameters(opt, advance=True):
+    """Counts one optimizer step (advance=True; dense Adam's bias corrections depend on it), forms this step's factors from the
+    optimizer's current learning rates and enqueues their store into the optimizer's device buffer on the current stream (the
+    values travel as launch arguments: the host is free at once)."""
+    groups = {g.get("name"): g for g in opt.param_groups}
+    tensors = [groups[n]["params"][0] if groups[n]["params"][0].numel() else None for n in _GROUP_ORDER]
+    fa, keep = _fused_adam_struct(opt, tensors, advance=advance)
+    dyn = enable_dynamic_hyperparameters(opt)
+    with _C.on_device(dyn.device):
+        _C.check(_C.lib().gsr_adam_set_dynamic(C.byref(fa), _C.ptr(dyn), _stream()))
+
+
+def prepare_for_graph_capture(device=None, slots=2):
+    """Call before `torch.cuda.graph(...)` around forwards of this module (after an eager warm-up of the shapes to capture): looks
+    at every status still in flight and keeps `slots` pinned status slots ready, so that the captured forward allocates no pinned
+    memory and queries nothing."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    p = _ws.pool(dev)
+    p.poll(wait=True)
+    while len(p.status_free) < slots:
+        p.status_free.append(torch.zeros(4, dtype=torch.int64).pin_memory())
+
+
+def graph_status_slot(device=None):
+    """(pinned status tensor, capacity, shape key) of the forward most recently captured into a HIP graph on this device:
+    int64[4] = [flags, num_rendered, longest tile list, -], rewritten by every replay (third word -1 until it arrives)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return getattr(_ws.pool(dev), "graph_status", None)
 
 
 def last_ticket(device=None):
@@ -266,9 +309,18 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         with _C.on_device(dev):
             pool = _ws.pool(dev)
-            pool.poll()                      # instance counts of earlier frames that have arrived meanwhile
-            ws = pool.acquire()              # state buffers of this forward (-> backward): grow-only, recycled
-            lease = _ws.Lease(pool, ws)
+            # Under HIP-graph capture (torch.cuda.graph) nothing may be queried, waited for or pinned: the frame is enqueued
+            # unverified for the capacity its shape has shown (warm up eagerly first), its state lives in a Workspace of its own
+            # (allocated from the graph's pool, never handed to eager calls) and its status slot is left to the graph's owner
+            # (`graph_status_slot`): a replay rewrites it, and a count beyond the capacity means what it means in mode "async".
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:
+                pool.poll()                  # instance counts of earlier frames that have arrived meanwhile
+                ws = pool.acquire()          # state buffers of this forward (-> backward): grow-only, recycled
+            else:
+                ws = _ws.Workspace(pool.device)
+                ws.stream = _C.raw_stream(dev.index)
+            lease = _ws.Lease(pool, ws, recycle=not capturing)
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)     # every entry is written by the projection kernel
@@ -287,6 +339,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             stream = _stream()
             try:
                 mode = _ws.forward_mode()
+                if capturing:
+                    if rs.debug or rs.prefiltered or key not in pool.capacity or not pool.status_free:
+                        raise _C.GsrError("gsr: a forward under graph capture needs an eager warm-up of the same shape first "
+                                          "(and neither debug nor prefiltered)")
+                    mode = "async"
                 if mode != "sync" and not rs.debug and not rs.prefiltered and P > 0:
                     # speculative: the whole frame is enqueued for the capacity this shape has shown so far.  "exact" then
                     # waits for THIS frame's count (it reaches pinned memory while the binning / compositing stages are still
@@ -327,10 +384,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                     # sentinel above being overwritten: no event on the stream (a record costs ~6 us of device time between the
                     # compositing kernel and the loss); an unverified frame's is waited for in order, behind an event
                     done = None
-                    if not verify or rerendered:       # (a re-rendered frame writes its status twice: wait for the last one)
-                        done = torch.cuda.Event()
-                        done.record()
-                    pool.pending.append((done, status, R, key, pool.ticket, verify))
+                    if capturing:
+                        pool.graph_status = (status, R, key)      # the graph's owner watches it (graph_status_slot)
+                    else:
+                        if not verify or rerendered:   # (a re-rendered frame writes its status twice: wait for the last one)
+                            done = torch.cuda.Event()
+                            done.record()
+                        pool.pending.append((done, status, R, key, pool.ticket, verify))
                 else:
                     # blocking read-back of num_rendered (the published rasterizer's one host synchronisation): debug mode,
                     # prefiltered=True (its "culled point" error is raised by this very call), or GSR_FORWARD_MODE=sync
@@ -398,8 +458,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             fused, split = None, False
             if P > 0 and _fused_optimizer is not None and ctx.raw_activations and dc is not None and colors_precomp is None:
                 split = _split_rows and not isinstance(_fused_optimizer, SparseGaussianAdam)
+                # factors kept in device memory (enable_dynamic_hyperparameters): an eager backward stores this step's values
+                # in front of its kernels; under graph capture nothing is counted or stored - whoever replays the graph does
+                # both per replay (push_dynamic_hyperparameters)
+                dynamic = getattr(_fused_optimizer, "_gsr_dynamic", None) is not None
+                capturing = dynamic and torch.cuda.is_current_stream_capturing()
                 fused = _fused_adam_struct(_fused_optimizer, (means3D, dc, sh, opacities, scales, rotations),
-                                           rows="with_instances" if split else None)
+                                           rows="with_instances" if split else None, advance=not capturing)
+                if fused is not None and dynamic and not capturing:
+                    _C.check(lib.gsr_adam_set_dynamic(C.byref(fused[0]), _C.ptr(_fused_optimizer._gsr_dynamic), _stream()))
             d_means2D = torch.empty(P, 3, dtype=torch.float32, device=dev)
             if fused is None and P > 0:
                 # ONE allocation for the gradients, geometry first: a data-parallel caller can exchange the four geometry tensors

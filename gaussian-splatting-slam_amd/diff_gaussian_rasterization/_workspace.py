@@ -94,12 +94,12 @@ class Lease:
     """Held by the autograd ctx; the workspace goes back to the pool when the ctx dies (after backward, or when the
     outputs are dropped without one)."""
 
-    def __init__(self, pool, ws):
-        self.pool, self.ws = pool, ws
+    def __init__(self, pool, ws, recycle=True):
+        self.pool, self.ws, self.recycle = pool, ws, recycle
 
     def release(self):
         ws, self.ws = self.ws, None
-        if ws is not None:
+        if ws is not None and self.recycle:      # (a workspace captured into a HIP graph belongs to that graph for good)
             self.pool.give_back(ws)
 
     def __del__(self):

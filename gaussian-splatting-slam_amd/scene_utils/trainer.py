@@ -93,6 +93,8 @@ class Trainer:
         self._rank1_fused = False
         self.rank1_fuse_adam = True      # exchange "sh_rank1": let the rebuilding kernel apply the SH groups' Adam step (dense HIP Adam)
         self._ticket_view = {}           # forward mode "async": rasterizer ticket -> view of the frames still unverified
+        self.graph_replay = False        # enable_graph_replay(): the single-view step as ONE HIP graph launch
+        self._graph = None
         self.rerun_views = 0             # ... and how many truncated frames were run again
 
     # statistics live in the model (reference: GaussianModel.xyz_gradient_accum / denom / max_radii2D)
@@ -120,6 +122,8 @@ class Trainer:
         """One optimizer step.  `view_idx`: one view (the reference's batch-1 step) or a list of views whose gradients are
         accumulated locally before the single cross-rank exchange and the single Adam step (gradient accumulation)."""
         views = list(view_idx) if isinstance(view_idx, (list, tuple)) else [view_idx]
+        if self.graph_replay and len(views) == 1 and self._graph_step(views[0]):
+            return self.last
         unverified = self.model.get_xyz.is_cuda and self._unverified_mode()
         if unverified:
             self._rerun_truncated_frames()
@@ -316,11 +320,144 @@ class Trainer:
         self._pending_sh_event = ev
         self.optimizer.zero_grad(set_to_none=True)
 
+    # ---- the single-view step as one HIP graph launch (launch-bound scenes: a few 10 k Gaussians, small images) ----
+    def enable_graph_replay(self, on=True, warmup=2):
+        """One rank, one view per step, optimizer folded into the backward ("hip_fused" / "hip_sparse_fused"), HIP loss: after
+        `warmup` eager steps per (model size, SH degree, image size) the whole step - forward, loss, backward, Adam, densification
+        statistics - is captured ONCE (torch.cuda.graph over the library's launches) and replayed with one host call per step.
+        What changes between steps lives in device memory: camera matrices and ground truth are copied into static buffers, the
+        optimizer's per-step factors are pushed in front of each replay (push_dynamic_hyperparameters), the forward runs
+        unverified for the capacity the shape has shown.  The status of step k is looked at before step k + 1 is launched: a
+        frame beyond the capacity was a no-op on the device (as in forward mode "async"); it is then run again eagerly, the
+        capacity is raised and the graph captured anew.  Steps the graph does not cover (several views, a densification due,
+        N > 1) run eagerly.  Same parameters, moments and statistics as the eager loop, bit for bit."""
+        if on and not (self.fuse_step and not self.distributed and self.separate_sh and self.model.get_xyz.is_cuda
+                       and self._gt_is_hip_loss()):
+            raise ValueError("graph replay needs one rank, a *_fused optimizer, separate_sh and the HIP loss on the HIP device")
+        self.graph_replay, self._graph_warmup = bool(on), int(warmup)
+        self._graph, self._graph_sig, self._graph_warm = None, None, {}
+        self.graph_stats = dict(captures=0, replays=0, eager_steps=0, overflow_reruns=0)
+
+    def _gt_is_hip_loss(self):
+        return self.loss_fn is training_loss_fused
+
+    def _graph_signature(self, cam):
+        m = self.model
+        return (int(m.get_xyz.shape[0]), int(m.active_sh_degree), int(cam.image_height), int(cam.image_width),
+                float(cam.FoVx), float(cam.FoVy), m._xyz.data_ptr(), m._features_rest.data_ptr())
+
+    def _graph_step(self, v):
+        """-> True if the step was done by a replay (or its eager stand-in), False: let the eager path do it."""
+        import diff_gaussian_rasterization as dgr
+        if self._densify_due(self.iteration + 1) or self.split_rows:
+            self._graph_settle()
+            return False
+        cam = self.cameras[v]
+        sig = self._graph_signature(cam)
+        if self._graph is None or self._graph_sig != sig:
+            self._graph_settle()
+            if self._graph_warm.get(sig, 0) < self._graph_warmup:       # the shape's capacity has to be known first
+                self._graph_warm[sig] = self._graph_warm.get(sig, 0) + 1
+                self.graph_stats["eager_steps"] += 1
+                return False
+            self._graph_capture(sig, cam, v)
+        if not self._graph_settle():          # the step before this one had to be run again eagerly: graph gone, start over
+            return self._graph_step(v)
+        g = self._graph_state
+        for dst, src in zip(g["cam_tensors"], (cam.world_view_transform, cam.full_proj_transform, cam.camera_center)):
+            dst.copy_(src, non_blocking=True)
+        g["gt"].copy_(self.gt_images[v], non_blocking=True)
+        if g["depth"] is not None:
+            g["depth"].copy_(self.depth_targets[v], non_blocking=True)
+        g["status"][2] = -1                                   # (rewritten by the replay's compositing kernel)
+        dgr.push_dynamic_hyperparameters(self.optimizer, advance=True)
+        self._graph.replay()
+        self.iteration += 1
+        self._graph_inflight = v
+        self.graph_stats["replays"] += 1
+        self.last = dict(loss=g["loss"], image=g["image"], radii=g["radii"])
+        return True
+
+    def _graph_capture(self, sig, cam, v):
+        import copy
+        import diff_gaussian_rasterization as dgr
+        m, dev = self.model, self.model.get_xyz.device
+        cam_s = copy.copy(cam)
+        cam_s.world_view_transform = cam.world_view_transform.clone()
+        cam_s.full_proj_transform = cam.full_proj_transform.clone()
+        cam_s.camera_center = cam.camera_center.clone()
+        gt = self.gt_images[v].clone()
+        depth = self.depth_targets[v].clone() if (self.depth_weight > 0 and self.depth_targets is not None) else None
+        if self._one is None or self._one.device != dev:
+            self._one = torch.ones((), dtype=torch.float32, device=dev)
+        dgr.enable_dynamic_hyperparameters(self.optimizer)
+        dgr.prepare_for_graph_capture(dev)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            pkg = self.render_fn(cam_s, m, self.pipe, self.bg, separate_sh=True)
+            loss = self.loss_fn(pkg["render"], gt, self.lambda_dssim)
+            if depth is not None:
+                from fused_ssim import l1_mean_loss
+                loss = loss + l1_mean_loss(pkg["depth"], depth, self.depth_weight)
+            dgr.fold_densification_stats_into_next_backward(m.xyz_gradient_accum, m.denom, m.max_radii2D)
+            dgr.fuse_optimizer_into_next_backward(self.optimizer, split_rows=False)
+            loss.backward(gradient=self._one)
+            taken = not dgr.fuse_pending() and not dgr.stats_pending()
+        if not taken:
+            dgr.fuse_optimizer_into_next_backward(None)
+            dgr.fold_densification_stats_into_next_backward(None, None, None)
+            raise RuntimeError("graph capture: the rasterizer's backward did not take the optimizer / statistics hand-off")
+        status, cap, key = dgr.graph_status_slot(dev)
+        self._graph, self._graph_sig = graph, sig
+        self._graph_state = dict(cam_tensors=(cam_s.world_view_transform, cam_s.full_proj_transform, cam_s.camera_center), gt=gt,
+                                 depth=depth, loss=loss.detach(), image=pkg["render"].detach(), radii=pkg["radii"], status=status,
+                                 capacity=cap, key=key, cam=cam_s)
+        self._graph_inflight = None
+        self.graph_stats["captures"] += 1
+
+    def _graph_settle(self):
+        """Waits for the status of the replay in flight (if any).  -> True: fine.  False: that frame had more tile instances than
+        the graph's binning state holds - its backward was a no-op on the device - so the step was counted back, run again
+        eagerly (verified), and the graph dropped (the next step captures a new one for the raised capacity)."""
+        import diff_gaussian_rasterization as dgr
+        from diff_gaussian_rasterization import _workspace as ws
+        v = getattr(self, "_graph_inflight", None)
+        if self._graph is None or v is None:
+            return True
+        g = self._graph_state
+        ws._wait_bounded(ws._StatusArrived(g["status"]), "the status of the replayed frame")
+        self._graph_inflight = None
+        flags, R = int(g["status"][0]), int(g["status"][1])
+        pool = ws.pool(self.model.get_xyz.device)
+        pool.stats["num_rendered"] = R
+        if R <= g["capacity"] and R >= 0:
+            return True
+        # truncated: nothing was updated (gsr_overflowed); undo the host-side count, learn the capacity, redo the view eagerly
+        for st in self.optimizer.state.values():
+            if "step" in st and float(st["step"]) > 0 and self.optimizer_kind == "hip":
+                st["step"] -= 1
+        self.iteration -= 1
+        pool.note(g["key"], R)
+        self._graph, self._graph_sig = None, None
+        self.graph_stats["overflow_reruns"] += 1
+        old = dgr.forward_mode()
+        dgr.set_forward_mode("exact")
+        try:
+            replay, self.graph_replay = self.graph_replay, False
+            self.step(v)
+        finally:
+            self.graph_replay = replay
+            dgr.set_forward_mode(old)
+        return False
+
     def finish(self):
         """Make the main stream wait for an SH update still in flight (call before reading the parameters outside step())."""
         ev = getattr(self, "_pending_sh_event", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
+        if self._graph is not None:
+            self._graph_settle()
         if self.model.get_xyz.is_cuda and self._unverified_mode():
             self._rerun_truncated_frames(wait=True)      # nothing truncated is left behind
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 
 enum {
   GSR_OK = 0,
@@ -226,7 +226,16 @@ typedef struct gsr_fused_adam {
   int64_t step[6];
   double beta1, beta2, eps;
   int32_t sparse;
+  /* Optional DEVICE pointer to GSR_ADAM_DYNAMIC_FLOATS floats (lr[6], lr / bias_correction1 [6], 1 / sqrt(bias_correction2) [6]),
+   * or NULL.  When set, the kernels read the per-step factors from there instead of deriving them from `lr` / `step`: the call
+   * then carries no per-step constant in its launch arguments and can be captured once into a HIP graph and replayed, with
+   * gsr_adam_set_dynamic enqueued in front of every replay. */
+  const float* dynamic;
 } gsr_fused_adam;
+#define GSR_ADAM_DYNAMIC_FLOATS 18
+/* Computes the factors of `opt` (its lr / step / betas / sparse, exactly as gsr_backward_adam would) and enqueues a one-workgroup
+ * kernel that stores them to `dynamic_dev`: the values travel as launch arguments, so the host may call it again at once. */
+int gsr_adam_set_dynamic(const gsr_fused_adam* opt, float* dynamic_dev, void* stream);
 int gsr_backward_adam(const gsr_settings* s, const gsr_gaussians* g, const int32_t* radii, const void* geometry_state,
                       const void* binning_state, const void* image_state, int64_t num_rendered, const float* dL_dcolor,
                       const float* dL_dinvdepth, void* scratch, size_t scratch_bytes, const gsr_grads* grads,
