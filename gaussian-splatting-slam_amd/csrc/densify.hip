@@ -236,11 +236,15 @@ int gsr_densify_apply(int64_t P, const void* workspace, const float* const* in_p
     gsr_set_error("densify_apply: bad arguments");
     return GSR_ERR_INVALID_ARGUMENT;
   }
-  if (P == 0) return 0;
+  // nothing to read, or nothing survives (every row pruned, none cloned or split): no row to write
+  if (P == 0 || n_keep + n_clone + n_child == 0) return 0;
   DensTensors t;
+  for (int p = 0; p < 6; p++) t.row[p] = row_floats[p];
   for (int k = 0; k < 18; k++) {
-    t.in[k] = in_ptrs[k];
-    t.out[k] = out_ptrs[k];
+    const bool empty_rows = t.row[k / 3] == 0;      // e.g. f_rest at SH degree 0: [P, 0, 3] - its pointers may be NULL
+    t.in[k] = empty_rows ? nullptr : in_ptrs[k];
+    t.out[k] = empty_rows ? nullptr : out_ptrs[k];
+    if (empty_rows) continue;
     if ((k % 3) != 0 && (in_ptrs[k] == nullptr) != (out_ptrs[k] == nullptr)) {
       gsr_set_error("densify_apply: optimizer state %d present on one side only", k);
       return GSR_ERR_INVALID_ARGUMENT;
@@ -250,7 +254,6 @@ int gsr_densify_apply(int64_t P, const void* workspace, const float* const* in_p
       return GSR_ERR_INVALID_ARGUMENT;
     }
   }
-  for (int p = 0; p < 6; p++) t.row[p] = row_floats[p];
   if (t.row[0] != 3 || t.row[4] != 3 || t.row[5] != 4) {
     gsr_set_error("densify_apply: xyz/scaling/rotation rows must be 3/3/4 floats");
     return GSR_ERR_INVALID_ARGUMENT;

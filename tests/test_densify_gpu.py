@@ -15,8 +15,8 @@ NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
 ATTRS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
 
 
-def _setup(P=6000, seed=3, with_moments=True):
-    raw = make_gaussians(P, 3, seed=seed, scale_factor=1.0)
+def _setup(P=6000, seed=3, with_moments=True, deg=3):
+    raw = make_gaussians(P, deg, seed=seed, scale_factor=1.0)
     gen = torch.Generator().manual_seed(seed + 1)
     raw.scaling += 1.2 * torch.randn(P, 3, generator=gen)                 # wide spread around percent_dense * extent
     raw.opacity[torch.rand(P, generator=gen) < 0.15] = -7.0              # some below min_opacity
@@ -178,3 +178,41 @@ def test_densification_stats_folded_into_backward_match_the_separate_kernel():
     assert float(res[True][1].sum()) > 1000
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+
+
+def test_densify_edge_cases_nothing_survives_and_sh_degree_zero():
+    """(a) every row below min_opacity and no gradient: the model ends up EMPTY (reference: prune_points with an all-true mask)
+    and still renders (background); (b) an SH-degree-0 model - f_rest is [P, 0, 3], no storage - densifies like any other.
+    Both were found by tools/extended_densify_sweep.py (the apply call refused the NULL pointers of empty tensors)."""
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import fibonacci_cameras
+    model, opt, accum, den = _setup(P=37, seed=9)
+    with torch.no_grad():
+        model._opacity.fill_(-9.0)
+    model.xyz_gradient_accum.zero_()
+    nk, nc, ns = model.densify_and_prune(0.0004, 0.005, 15.0, None, None, seed=1)
+    assert (nk, nc, ns) == (0, 0, 0) and model.get_xyz.shape[0] == 0 and model._features_rest.shape == (0, 15, 3)
+    for g in opt.param_groups:
+        assert g["params"][0].shape[0] == 0
+    cam = fibonacci_cameras(1, 64, 48, seed=2, device="cuda")[0]
+    bg = torch.tensor([0.3, 0.2, 0.1], device="cuda")
+    img = render(cam, model, PipelineParams(), bg)["render"]
+    assert torch.equal(img, bg[:, None, None].expand_as(img))
+    # (b)
+    model, opt, accum, den = _setup(P=4001, seed=10, deg=0)
+    assert model._features_rest.numel() == 0
+    params = {n: getattr(model, a).detach().cpu().clone() for n, a in zip(NAMES, ATTRS)}
+    moments = {}
+    for n, a in zip(NAMES, ATTRS):
+        st = opt.state.get(getattr(model, a), {})
+        moments[n] = (st["exp_avg"].cpu().clone(), st["exp_avg_sq"].cpu().clone()) if "exp_avg" in st else None
+    ref_p, ref_m, info = DO.densify_and_prune(params, moments, accum.clone(), den.clone(), model.max_radii2D.cpu().clone(), 0.0004,
+                                              0.005, 15.0, 20, model.percent_dense, normal_samples=None)
+    nk, nc, ns, src = model.densify_and_prune(0.0004, 0.005, 15.0, 20, None, seed=3, return_source=True)
+    kind = info["kind"]
+    assert (nk, nc, 2 * ns) == (int((kind == 0).sum()), int((kind == 1).sum()), int((kind == 2).sum())) and nc > 10 and ns > 10
+    assert torch.equal(src.cpu().long(), info["source"])
+    det = kind != 2
+    for n, a in zip(NAMES, ATTRS):
+        got = getattr(model, a).detach().cpu()
+        assert got.shape == ref_p[n].shape and torch.equal(got[det], ref_p[n][det]), n
