@@ -121,7 +121,8 @@ int gsr_adam_step(int32_t count, float* const* params, const float* const* grads
 int gsr_sparse_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                          float* const* exp_avg_sq, const int64_t* numel, const float* lr, int64_t N,
                          const uint8_t* visible, double beta1, double beta2, double eps, void* stream) {
-  if (count < 0 || count > GSR_ADAM_MAX_TENSORS || N <= 0 || !visible) {
+  if (N == 0) return 0;     // an empty model (everything pruned): nothing to update
+  if (count < 0 || count > GSR_ADAM_MAX_TENSORS || N < 0 || !visible) {
     gsr_set_error("sparse adam: bad arguments");
     return GSR_ERR_INVALID_ARGUMENT;
   }

@@ -216,3 +216,25 @@ def test_densify_edge_cases_nothing_survives_and_sh_degree_zero():
     for n, a in zip(NAMES, ATTRS):
         got = getattr(model, a).detach().cpu()
         assert got.shape == ref_p[n].shape and torch.equal(got[det], ref_p[n][det]), n
+
+
+@pytest.mark.parametrize("kind", ["hip", "hip_sparse", "hip_fused", "hip_sparse_fused"])
+def test_training_goes_on_after_the_model_was_pruned_to_empty(kind):
+    """min_opacity above every opacity: the first densification prunes the model to ZERO rows; the steps after it (render = the
+    background, empty gradients, an optimizer step over nothing) must simply run (found by tools/extended_fused_sweep.py
+    --densify: SparseGaussianAdam's launch refused N = 0)."""
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import fibonacci_cameras, Trainer
+    cams = fibonacci_cameras(2, 96, 64, seed=4, device="cuda")
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    gts = {i: torch.rand(3, 64, 96, device="cuda") for i in range(2)}
+    model = GaussianModel.from_raw(make_gaussians(500, 2, seed=6, scale_factor=0.8).to("cuda"))
+    tr = Trainer(model, cams, gts, render, PipelineParams(), bg, separate_sh=True, optimizer=kind)
+    tr.enable_densification(extent=4.4, from_iter=1, until_iter=100, interval=2, opacity_reset_interval=50, grad_threshold=1e-5,
+                            min_opacity=1.1)
+    for it in range(6):
+        tr.step(it % 2)
+    tr.finish()
+    torch.cuda.synchronize()
+    assert model.get_xyz.shape[0] == 0
+    assert torch.equal(tr.last["image"], bg[:, None, None].expand(3, 64, 96))

@@ -17,8 +17,10 @@ import torch  # noqa: E402
 from gaussian_renderer import render, PipelineParams  # noqa: E402
 from scene_utils import make_gaussians, fibonacci_cameras, GaussianModel, Trainer  # noqa: E402
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+DENSIFY = "--densify" in sys.argv    # ... with the reference's densify / prune / opacity-reset schedule compressed into the run
+args_ = [a for a in sys.argv[1:] if a != "--densify"]
+first = int(args_[0]) if len(args_) > 0 else 0
+count = int(args_[1]) if len(args_) > 1 else 100
 bad, t0 = [], time.time()
 for seed in range(first, first + count):
     g = torch.Generator().manual_seed(9000 + seed)
@@ -36,12 +38,16 @@ for seed in range(first, first + count):
     with torch.no_grad():
         gts = {i: render(c, teacher, pipe, bg)["render"].clone() for i, c in enumerate(cams)}
     runs = []
+    thr, min_op = u(1e-6, 1e-4), u(0.001, 0.2)       # (the high end prunes a model to EMPTY behind an opacity reset: that runs too)
     try:
         for fused in (False, True):
             model = GaussianModel.from_raw(make_gaussians(P, deg, seed=9300 + seed, scale_factor=sf).to("cuda"))
             model.active_sh_degree = deg
             tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True, optimizer=kind + ("_fused" if fused else ""))
-            for it in range(5):
+            if DENSIFY:
+                tr.enable_densification(extent=4.4, from_iter=2, until_iter=100, interval=4, opacity_reset_interval=9,
+                                        grad_threshold=thr, min_opacity=min_op, seed=seed)
+            for it in range(14 if DENSIFY else 5):
                 tr.step(it % 3)
             tr.finish()
             torch.cuda.synchronize()
@@ -52,9 +58,10 @@ for seed in range(first, first + count):
                 s_ = tr.optimizer.state.get(p_, {})
                 st += [p_.detach().clone()] + ([s_["exp_avg"].clone(), s_["exp_avg_sq"].clone()] if "exp_avg" in s_ else [])
             runs.append(st + [model.xyz_gradient_accum.clone(), model.denom.clone(), model.max_radii2D.clone()])
-        assert len(runs[0]) == len(runs[1])
+        assert len(runs[0]) == len(runs[1]), ("state count", len(runs[0]), len(runs[1]))
         for i, (a, b) in enumerate(zip(*runs)):
-            assert a.shape == b.shape and torch.equal(a, b), (i, float((a - b).abs().max()) if a.numel() else 0.0)
+            assert a.shape == b.shape, ("shape", i, tuple(a.shape), tuple(b.shape))
+            assert torch.equal(a, b), ("value", i, float((a - b).abs().max()) if a.numel() else 0.0)
     except Exception as e:      # noqa: BLE001
         bad.append(seed)
         print(f"seed {seed} (P {P}, {W}x{H}, deg {deg}, {kind}, aa {pipe.antialiasing}): {type(e).__name__}: {str(e)[:200]}", flush=True)
