@@ -349,8 +349,8 @@ class Trainer:
     def _graph_step(self, v):
         """-> True if the step was done by a replay (or its eager stand-in), False: let the eager path do it."""
         import diff_gaussian_rasterization as dgr
-        if self._densify_due(self.iteration + 1) or self.split_rows:
-            self._graph_settle()
+        if self._densify_due(self.iteration + 1) or self.split_rows or int(self.model.get_xyz.shape[0]) == 0:
+            self._graph_settle()          # (an empty model - everything pruned - has nothing to capture: eager)
             return False
         cam = self.cameras[v]
         sig = self._graph_signature(cam)

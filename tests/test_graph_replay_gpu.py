@@ -73,3 +73,38 @@ def test_replayed_frame_beyond_the_graphs_capacity_is_rerun_and_the_graph_recapt
     assert stats["overflow_reruns"] == 1 and stats["captures"] == 3 and it_ref == it_got
     for i, (a, b) in enumerate(zip(ref, got)):
         assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize("min_opacity", [0.005, 1.1])
+def test_graph_replay_across_densifications(min_opacity):
+    """A densification changes the model size: the steps around it run eagerly, the graph is captured anew for the new size -
+    and a model pruned to EMPTY (min_opacity above every opacity) simply goes on eagerly.  Same end state as the eager loop."""
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import make_gaussians, fibonacci_cameras, GaussianModel, Trainer
+    dev = "cuda"
+    cams = fibonacci_cameras(3, 160, 96, seed=51, device=dev)
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams()
+    teacher = GaussianModel.from_raw(make_gaussians(3000, 1, seed=52, scale_factor=0.8).to(dev), requires_grad=False)
+    with torch.no_grad():
+        gts = {i: render(c, teacher, pipe, bg)["render"].clone() for i, c in enumerate(cams)}
+    ends = []
+    for graph in (False, True):
+        model = GaussianModel.from_raw(make_gaussians(3000, 1, seed=53, scale_factor=0.8).to(dev))
+        tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True, optimizer="hip_fused")
+        tr.enable_densification(extent=4.4, from_iter=3, until_iter=100, interval=6, opacity_reset_interval=50,
+                                grad_threshold=2e-5, min_opacity=min_opacity, seed=7)
+        if graph:
+            tr.enable_graph_replay(warmup=1)
+        for it in range(20):
+            tr.step(it % 3)
+        tr.finish()
+        torch.cuda.synchronize()
+        ends.append(([p.detach().clone() for p in model.parameters()], tr.graph_stats if graph else None))
+    (ref, _), (got, stats) = ends
+    for a, b in zip(ref, got):
+        assert a.shape == b.shape and torch.equal(a, b)
+    if min_opacity < 1:
+        assert stats["captures"] >= 3 and stats["replays"] >= 8 and ref[0].shape[0] > 3000
+    else:
+        assert ref[0].shape[0] == 0 and stats["captures"] == 1

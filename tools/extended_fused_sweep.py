@@ -18,7 +18,8 @@ from gaussian_renderer import render, PipelineParams  # noqa: E402
 from scene_utils import make_gaussians, fibonacci_cameras, GaussianModel, Trainer  # noqa: E402
 
 DENSIFY = "--densify" in sys.argv    # ... with the reference's densify / prune / opacity-reset schedule compressed into the run
-args_ = [a for a in sys.argv[1:] if a != "--densify"]
+GRAPH = "--graph" in sys.argv        # second run: the step replayed from a HIP graph (Trainer.enable_graph_replay) instead of eager
+args_ = [a for a in sys.argv[1:] if a not in ("--densify", "--graph")]
 first = int(args_[0]) if len(args_) > 0 else 0
 count = int(args_[1]) if len(args_) > 1 else 100
 bad, t0 = [], time.time()
@@ -43,11 +44,14 @@ for seed in range(first, first + count):
         for fused in (False, True):
             model = GaussianModel.from_raw(make_gaussians(P, deg, seed=9300 + seed, scale_factor=sf).to("cuda"))
             model.active_sh_degree = deg
-            tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True, optimizer=kind + ("_fused" if fused else ""))
+            tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True,
+                         optimizer=kind + ("_fused" if (fused or GRAPH) else ""))
+            if GRAPH and fused:
+                tr.enable_graph_replay(warmup=1)
             if DENSIFY:
                 tr.enable_densification(extent=4.4, from_iter=2, until_iter=100, interval=4, opacity_reset_interval=9,
                                         grad_threshold=thr, min_opacity=min_op, seed=seed)
-            for it in range(14 if DENSIFY else 5):
+            for it in range(14 if DENSIFY else (9 if GRAPH else 5)):
                 tr.step(it % 3)
             tr.finish()
             torch.cuda.synchronize()
