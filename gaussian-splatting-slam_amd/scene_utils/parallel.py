@@ -287,16 +287,19 @@ class ShardedStep:
     def step(self):
         world, rank, c, P0 = self.world, self.rank, self.c, self.P0
         nccl = dist.get_backend(self.group) == "nccl"
-        works = []
+        works, scaled = [], []
         for p, shard, rest in self.items:
             g = p.grad if p.grad is not None else torch.zeros_like(p)
             g = g.contiguous()
             if c > 0:
                 if nccl:
+                    # (SUM, scaled below: RCCL 2.26's ONE-rank reduce-scatter with AVG leaves the last element of some
+                    # sizes unwritten - 5745 floats, found by tools/extended_exchange_sweep.py; SUM is the well-trodden path)
                     out = torch.empty_like(shard)
-                    works.append(dist.reduce_scatter_tensor(out, g[:P0], op=dist.ReduceOp.AVG, group=self.group,
+                    works.append(dist.reduce_scatter_tensor(out, g[:P0], op=dist.ReduceOp.SUM, group=self.group,
                                                             async_op=True))
                     shard.grad = out
+                    scaled.append(out)
                 else:       # gloo has no reduce-scatter: all-reduce, keep the own rows (CPU rehearsal of the same arithmetic)
                     dist.all_reduce(g[:P0], op=dist.ReduceOp.SUM, group=self.group)
                     shard.grad = g[rank * c:(rank + 1) * c] * (1.0 / world)
@@ -309,6 +312,8 @@ class ShardedStep:
                     rest.grad = g[P0:] * (1.0 / world)
         for w in works:
             w.wait()
+        for out in scaled:
+            out.mul_(1.0 / world)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         works = []

@@ -196,10 +196,10 @@ def test_sharded_step_rccl_branches_with_an_in_process_group(monkeypatch):
         return vals
 
     def reduce_scatter_tensor(out, inp, op=None, group=None, async_op=False):
-        assert op == dist.ReduceOp.AVG
+        assert op == dist.ReduceOp.SUM               # (ShardedStep scales the shard itself: see scene_utils/parallel.py)
         vals = everyone(inp)
         c = out.shape[0]
-        out.copy_(sum(v[tl.rank * c:(tl.rank + 1) * c] for v in vals) / world)
+        out.copy_(sum(v[tl.rank * c:(tl.rank + 1) * c] for v in vals))
         return Work()
 
     def all_reduce(t, op=None, group=None, async_op=False):
