@@ -126,10 +126,27 @@ class Trainer:
             return self.last
         unverified = self.model.get_xyz.is_cuda and self._unverified_mode()
         if unverified:
-            self._rerun_truncated_frames()
+            # the status of the previous step's frame is waited for HERE (it left the device when that frame's compositing kernel
+            # started, i.e. long ago unless the host runs more than a step ahead): a truncated frame is run again before the
+            # next view is touched, so the updates keep the order of the default mode
+            self._rerun_truncated_frames(wait=True)
+            # A truncated frame is only harmless where its backward IS the whole step: optimizer (and statistics) folded into it,
+            # so the device-side guard leaves parameters, moments and statistics untouched and the view can simply be run again.
+            # Any other step - optimizer as its own launch (a zero-gradient Adam step still moves parameters), a densification
+            # due, several views, N > 1 - verifies its frames like the default mode does.
+            unverified = (self.fuse_step and not self.distributed and len(views) == 1 and self.separate_sh
+                          and not self._densify_due(self.iteration + 1))
+        exact_here = self.model.get_xyz.is_cuda and self._unverified_mode() and not unverified
+        if exact_here:
+            import diff_gaussian_rasterization as dgr
+            dgr.set_forward_mode("exact")
         for n, v in enumerate(views):
             cam = self.cameras[v]
-            pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh)
+            try:
+                pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh)
+            finally:
+                if exact_here and n + 1 == len(views):
+                    dgr.set_forward_mode("async")
             if unverified:
                 import diff_gaussian_rasterization as dgr
                 self._ticket_view[dgr.last_ticket(self.model.get_xyz.device)] = v
@@ -248,6 +265,7 @@ class Trainer:
                 for st in self.optimizer.state.values():
                     if "step" in st and float(st["step"]) > 0:
                         st["step"] -= 1
+            self.iteration -= 1              # ... and neither may the iteration count (densification / reset schedule)
             self.rerun_views += 1
             dgr.set_forward_mode("exact")
             try:
