@@ -294,7 +294,7 @@ class ShardedStep:
             if c > 0:
                 if nccl:
                     # (SUM, scaled below: RCCL 2.26's ONE-rank reduce-scatter with AVG leaves the last element of some
-                    # sizes unwritten - 5745 floats, found by tools/extended_exchange_sweep.py; SUM is the well-trodden path)
+                    # sizes unwritten - 5745 floats, found by tests/sweeps/extended_exchange_sweep.py; SUM is the well-trodden path)
                     out = torch.empty_like(shard)
                     works.append(dist.reduce_scatter_tensor(out, g[:P0], op=dist.ReduceOp.SUM, group=self.group,
                                                             async_op=True))

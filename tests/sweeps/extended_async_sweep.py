@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extended sweep of the unverified forward mode under capacity trouble (GPU box, repo root):
-    python tools/extended_async_sweep.py [first] [count]
+    python tests/sweeps/extended_async_sweep.py [first] [count]
 Per seed a random small training run (both folded optimizers, SH 0..3, with / without densification) in the default mode against
 the same run in forward mode "async" where, at random steps, the workspace pool's capacity estimate is cut to a fraction of what
 the frames need: those frames are composited from truncated lists, their backward must be a no-op on the device, the Trainer must
@@ -9,7 +9,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extended sweep of densify_and_prune against its CPU restatement (GPU box, repo root):
-    python tools/extended_densify_sweep.py [first] [count]
+    python tests/sweeps/extended_densify_sweep.py [first] [count]
 Random model sizes (1 .. 30 000 rows, odd counts), scale spreads, gradient thresholds, extents, screen-size limits, with and
 without optimizer moments: the rows kept / cloned / split, their order, every parameter and moment of kept and cloned rows and
 everything but the sampled position of split rows must equal oracle/densify_oracle.py exactly (tests/test_densify_gpu.py checks
@@ -9,7 +9,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extended sweep of the two-rank data-parallel schedules (GPU box, repo root; two ranks share the box's one GPU, gloo between them):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29655 \\
-        tools/extended_dp_sweep.py [first] [count]
+        tests/sweeps/extended_dp_sweep.py [first] [count]
 Per seed a random small scene: for both optimizers the plain synchronous exchange against the side-stream overlap (bit for bit,
 and both ranks identical), `visible_rows` and `sharded` against `allreduce` (bit for bit), `sh_rank1` plain against overlapped
 against un-fused (bit for bit) and against `allreduce` (fp32 rounding) - tests/dp_overlap_worker.py on random shapes."""
@@ -9,7 +9,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extended sweep of the N > 1 training schedules on a process group of ONE rank over real RCCL (GPU box, repo root):
-    python tools/extended_exchange_sweep.py [first] [count]
+    python tests/sweeps/extended_exchange_sweep.py [first] [count]
 Per seed a random small scene (odd sizes, SH degree 0..3, dense Adam or SparseGaussianAdam, with / without densification): the
 plain single-GPU loop against every exchange form and the side-stream overlap where it applies.  The mean over one rank is the
 rank's own gradient, so `allreduce`, `visible_rows` and `sharded` must reproduce the plain loop bit for bit and `sh_rank1` to fp32
@@ -10,7 +10,7 @@ import socket
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

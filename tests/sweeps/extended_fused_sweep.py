@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extended bit-equality sweep of the optimizer folded into the rasterizer backward (GPU box, repo root):
-    python tools/extended_fused_sweep.py [first] [count]
+    python tests/sweeps/extended_fused_sweep.py [first] [count]
 Per seed a random small scene (odd Gaussian counts and image sizes, SH degree 0..3, dense Adam or SparseGaussianAdam, anti-
 aliasing on / off, a few views): N training steps with the optimizer as its own launch against the same steps with the update
 folded into the backward's last kernel (gsr_backward_adam).  Parameters, both moments and the densification statistics must be
@@ -9,7 +9,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

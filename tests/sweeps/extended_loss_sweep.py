@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Extended sweep of the fused loss kernels (GPU box, repo root):  python tools/extended_loss_sweep.py [first] [count]
+"""Extended sweep of the fused loss kernels (GPU box, repo root):  python tests/sweeps/extended_loss_sweep.py [first] [count]
 Random image sizes from 1x1 up (narrower than the 11-tap window included), 1-4 planes, random lambda: fused_l1_ssim_loss,
 fused_ssim (map form) and l1_mean_loss - value and gradient - against the pure-PyTorch restatement in float64
 (oracle/loss_oracle.py = reference utils/loss_utils.py:100-159 + train.py:114-121)."""
@@ -7,7 +7,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extended bit-equality sweep over the forward modes and binning forms (GPU box, repo root):
-    python tools/extended_modes_sweep.py [first] [count]
+    python tests/sweeps/extended_modes_sweep.py [first] [count]
 Per seed a scene of tests/test_sweep_gpu.py's generator, rendered forward + backward through (a) the blocking forward with the
 global depth sort ("sync" + global binning: the published structure), (b) the default - speculative, verified, tile-local binning
 - (c) the unverified mode, each with a workspace pool that has never seen the shape (so the capacity guess, the verify and, when
@@ -9,7 +9,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

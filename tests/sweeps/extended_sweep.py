@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Extended run of tests/test_sweep_gpu.py's seeded sweep (GPU box, repo root):  python tools/extended_sweep.py [first] [count]
+"""Extended run of tests/test_sweep_gpu.py's seeded sweep (GPU box, repo root):  python tests/sweeps/extended_sweep.py [first] [count]
 Every case forward + backward against the float64 oracle with the tolerances of tests/test_parity_gpu.py; failures are listed, not
 raised, so one run shows all of them.  (The test suite keeps seeds 0..23; this is for spare GPU minutes.)
 
@@ -12,7 +12,7 @@ import sys
 import time
 import traceback
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

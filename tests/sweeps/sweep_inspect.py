@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Why did a seed of tools/extended_sweep.py miss the tolerance?  python tools/sweep_inspect.py <seed> [<seed> ...]   (GPU box)
+"""Why did a seed of tests/sweeps/extended_sweep.py miss the tolerance?  python tests/sweeps/sweep_inspect.py <seed> [<seed> ...]   (GPU box)
 Per seed: forward deviations of the HIP path and of the fp32 oracle against the float64 oracle, and per gradient tensor the
 relative L2 error of (a) the HIP path, (b) the fp32 oracle, (c) the float64 oracle itself after moving every opacity logit by
 +-1e-6.  (a) == (b): fp32 rounding; (c) of the same size as (a): the scene sits on a discontinuity (alpha >= 1/255, T < 1e-4,

@@ -183,7 +183,7 @@ def test_densification_stats_folded_into_backward_match_the_separate_kernel():
 def test_densify_edge_cases_nothing_survives_and_sh_degree_zero():
     """(a) every row below min_opacity and no gradient: the model ends up EMPTY (reference: prune_points with an all-true mask)
     and still renders (background); (b) an SH-degree-0 model - f_rest is [P, 0, 3], no storage - densifies like any other.
-    Both were found by tools/extended_densify_sweep.py (the apply call refused the NULL pointers of empty tensors)."""
+    Both were found by tests/sweeps/extended_densify_sweep.py (the apply call refused the NULL pointers of empty tensors)."""
     from gaussian_renderer import render, PipelineParams
     from scene_utils import fibonacci_cameras
     model, opt, accum, den = _setup(P=37, seed=9)
@@ -221,7 +221,7 @@ def test_densify_edge_cases_nothing_survives_and_sh_degree_zero():
 @pytest.mark.parametrize("kind", ["hip", "hip_sparse", "hip_fused", "hip_sparse_fused"])
 def test_training_goes_on_after_the_model_was_pruned_to_empty(kind):
     """min_opacity above every opacity: the first densification prunes the model to ZERO rows; the steps after it (render = the
-    background, empty gradients, an optimizer step over nothing) must simply run (found by tools/extended_fused_sweep.py
+    background, empty gradients, an optimizer step over nothing) must simply run (found by tests/sweeps/extended_fused_sweep.py
     --densify: SparseGaussianAdam's launch refused N = 0)."""
     from gaussian_renderer import render, PipelineParams
     from scene_utils import fibonacci_cameras, Trainer
