@@ -21,16 +21,20 @@ from helpers import run_hip, run_oracle, upstream_grads  # noqa: E402
 from test_parity_gpu import check_forward, check_grads  # noqa: E402
 from test_sweep_gpu import _case  # noqa: E402
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+COV = "--cov" in sys.argv
+_a = [a for a in sys.argv[1:] if a != "--cov"]
+first = int(_a[0]) if len(_a) > 0 else 24
+count = int(_a[1]) if len(_a) > 1 else 200
 torch.set_num_threads(16)
 bad, flips, t0 = [], [], time.time()
 for seed in range(first, first + count):
     try:
         raw, cam, deg, mode, aa, bg, sm = _case(seed)
         gc, gd = upstream_grads(cam.image_height, cam.image_width, seed=seed)
-        ref = run_oracle(raw, cam, deg, bg, torch.float64, mode=mode, antialiasing=aa, scale_modifier=sm, gc=gc, gd=gd)
-        out = run_hip(raw, cam, deg, bg, mode=mode, antialiasing=aa, scale_modifier=sm, gc=gc, gd=gd)
+        cov = COV and seed % 2 == 0            # --cov: every other case hands in a precomputed 3-D covariance instead of scale / rotation
+        ref = run_oracle(raw, cam, deg, bg, torch.float64, mode=mode, antialiasing=aa, scale_modifier=sm, gc=gc, gd=gd,
+                         cov_precomp=cov)
+        out = run_hip(raw, cam, deg, bg, mode=mode, antialiasing=aa, scale_modifier=sm, gc=gc, gd=gd, cov_precomp=cov)
         try:
             check_forward(out, ref)
         except AssertionError as e:
