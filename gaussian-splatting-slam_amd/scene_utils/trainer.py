@@ -135,17 +135,17 @@ class Trainer:
             # Any other step - optimizer as its own launch (a zero-gradient Adam step still moves parameters), a densification
             # due, several views, N > 1 - verifies its frames like the default mode does.
             unverified = (self.fuse_step and not self.distributed and len(views) == 1 and self.separate_sh
-                          and not self._densify_due(self.iteration + 1))
+                          and not self._densify_due(self.iteration + 1) and not getattr(self, "_fold_refused", False))
         exact_here = self.model.get_xyz.is_cuda and self._unverified_mode() and not unverified
-        if exact_here:
-            import diff_gaussian_rasterization as dgr
-            dgr.set_forward_mode("exact")
         for n, v in enumerate(views):
             cam = self.cameras[v]
+            if exact_here:
+                import diff_gaussian_rasterization as dgr
+                dgr.set_forward_mode("exact")
             try:
                 pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh)
             finally:
-                if exact_here and n + 1 == len(views):
+                if exact_here:
                     dgr.set_forward_mode("async")
             if unverified:
                 import diff_gaussian_rasterization as dgr
@@ -190,6 +190,18 @@ class Trainer:
             folded = False
             if fold:
                 folded = not dgr.fuse_pending()
+                if not folded and unverified:
+                    # the renderer did not take the optimizer (a model wrapper without raw parameters ...): this frame ran
+                    # unverified and its update is about to happen as a launch of its own - look at its status NOW, and from
+                    # here on verify every frame
+                    self._fold_refused = True
+                    t = dgr.last_ticket(self.model.get_xyz.device)
+                    if t in dgr.take_overflowed(self.model.get_xyz.device, wait=True):
+                        self._ticket_view.pop(t, None)
+                        dgr.fuse_optimizer_into_next_backward(None)
+                        dgr.fold_densification_stats_into_next_backward(None, None, None)
+                        self.optimizer.zero_grad(set_to_none=True)
+                        return self.step(view_idx)          # (truncated: zero gradients, nothing applied yet - once more, verified)
                 if not folded:
                     dgr.fuse_optimizer_into_next_backward(None)     # the rasterizer could not take it: plain step below
             if fold_stats and dgr.stats_pending():
