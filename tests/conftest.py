@@ -12,6 +12,15 @@ for p in (ROOT, PKG, os.path.dirname(os.path.abspath(__file__))):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The CPU oracles are torch code: let torch use the CPUs this process really has (a GPU box gives a 16-CPU share of a much
+    # bigger host; `os.cpu_count()` threads on that share spin against each other - an oracle-heavy test then takes minutes
+    # instead of seconds, which is what a test that "hung" once in round 3 most likely was)
+    import torch
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:       # noqa: BLE001
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(n, int(os.environ.get("GSR_TEST_THREADS", "16")))))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -14,6 +14,8 @@ for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(
     sys.path.insert(0, p)
 import torch  # noqa: E402
 
+torch.set_num_threads(16)      # (the box's CPU share; torch's default there is 128 threads on a 16-CPU quota)
+
 import diff_gaussian_rasterization as dgr  # noqa: E402
 from diff_gaussian_rasterization import _workspace as ws  # noqa: E402
 from gaussian_renderer import render, PipelineParams  # noqa: E402

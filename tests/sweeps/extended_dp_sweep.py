@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402
+
+torch.set_num_threads(16)      # (the box's CPU share; torch's default there is 128 threads on a 16-CPU quota)
 import torch.distributed as dist  # noqa: E402
 
 os.environ["BENCH_SHARE_GPU"] = "1"

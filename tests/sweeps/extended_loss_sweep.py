@@ -12,6 +12,8 @@ for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(
     sys.path.insert(0, p)
 import torch  # noqa: E402
 
+torch.set_num_threads(16)      # (the box's CPU share; torch's default there is 128 threads on a 16-CPU quota)
+
 from fused_ssim import fused_l1_ssim_loss, fused_ssim, l1_mean_loss  # noqa: E402
 from oracle import loss_oracle as LO  # noqa: E402
 
