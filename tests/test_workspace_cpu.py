@@ -116,3 +116,28 @@ def test_verified_frames_need_no_event_the_status_sentinel_tells():
     a[1], a[2] = 4000, -(1 << 32) + 1200          # high half still the sentinel's (0xFFFFFFFF): only the low half counts
     p.poll()
     assert not p.pending and p.longest_list[key] == 3000 and len(p.status_free) == 2
+
+
+def test_dc_gradient_tail_row_is_recognised_only_for_the_backwards_own_tensor():
+    """The backward returns its dc gradient with three spare floats behind it; `dc_grad_tail_row` hands out the [P + 1, 3] view over
+    both only for THAT tensor (same storage position and size) - a copy, another tensor or a stale record gets None and the caller
+    concatenates."""
+    import diff_gaussian_rasterization as dgr
+    P = 37
+    xyz, op, sc, rot, dc, rest, _, _ = dgr._grad_arena("cpu", (((P, 3), 0), ((P, 1), 0), ((P, 3), 0), ((P, 4), 0), ((P, 1, 3), 3),
+                                                               ((P, 15, 3), 0), (None, 0), (None, 0)))
+    old = dgr._last_dc_grad
+    try:
+        dgr._last_dc_grad = (dc.data_ptr(), dc.numel())
+        dc.copy_(torch.arange(3 * P, dtype=torch.float32).view(P, 1, 3))
+        rest.fill_(-5.0)
+        tail = dgr.dc_grad_tail_row(dc)
+        assert tail is not None and tail.shape == (P + 1, 3) and tail.data_ptr() == dc.data_ptr()
+        assert torch.equal(tail[:P], dc.view(P, 3))
+        tail[P] = torch.tensor([7.0, 8.0, 9.0])
+        assert bool((rest == -5.0).all())                      # the spare row lies in front of the next tensor
+        assert dgr.dc_grad_tail_row(dc.clone()) is None and dgr.dc_grad_tail_row(xyz.view(P, 1, 3)) is None
+        dgr._last_dc_grad = None
+        assert dgr.dc_grad_tail_row(dc) is None
+    finally:
+        dgr._last_dc_grad = old
