@@ -31,6 +31,8 @@
 extern "C" {
 #endif
 
+/* 5: gsr_fused_adam.dynamic + gsr_adam_set_dynamic (optimizer factors in device memory, for HIP-graph replay), gsr_l1_mean_*;
+ * 4: gsr_forward_async(num_rendered_out) / gsr_forward_rerender (verified speculation), gsr_sh_rank1_*; 3: gsr_backward_adam */
 #define GSR_ABI_VERSION 5
 
 enum {
