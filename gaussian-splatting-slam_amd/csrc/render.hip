@@ -148,7 +148,14 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   const int tile = blockIdx.x;
   // non-blocking forward: the frame's status words (flags, num_rendered, longest tile list - final since the previous
   // kernel) go straight to the caller's pinned host slot; a 32-byte hipMemcpyAsync here cost ~10 us of stream time
-  if (status_dst && blockIdx.x == 0 && threadIdx.x < 8) status_dst[threadIdx.x] = status_src[threadIdx.x];
+  // Word 4 (the longest tile list) is the one the host's sentinel sits in (_workspace.py _StatusArrived): it leaves LAST, behind a
+  // system-scope fence, so a host that sees it overwritten also sees flags and num_rendered of THIS frame (not a replay's
+  // predecessor's).
+  if (status_dst && blockIdx.x == 0 && threadIdx.x < 8) {
+    if (threadIdx.x != 4) status_dst[threadIdx.x] = status_src[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 4) status_dst[4] = status_src[4];
+  }
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int px = tile_x * GSR_TILE + (w & 1) * 8 + (lane & 7);
@@ -438,11 +445,54 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
 // 31 KB), and a sub-block the Gaussian misses still costs only the 9-instruction reject test behind a scalar skip.
 // Summation order is fixed (sub-blocks 0..3 in a lane, then the halving tree): bitwise reproducible like the first form.
 // ---------------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
+// (round 4) Sub-block masks, computed where the records are STAGED.  The lane that copies list entry e into LDS also decides,
+// for that entry, which of the tile's four 8x8 sub-blocks the Gaussian can reach at all: bit s is set unless the maximum of the
+// (concave) log2-power over the hull of sub-block s's pixel centres stays below the record's cut-off pmin' (= alpha < 1/255
+// everywhere, with the record's own margin), or every pixel of the sub-block finished in front of this entry (entry1 >
+// sub_last[s]).  64 entries are tested by 64 lanes at once (~170 VALU wave-instructions per BATCH instead of 8 VALU + two
+// ballots + two branches per (entry, sub-block) in the entry loop), and the loop reads an entry's mask into an SGPR
+// (v_readlane) and skips missed sub-blocks on the scalar unit.  The test is conservative (max over the continuous rectangle >=
+// max over its pixel centres; slack 2e-6 x the magnitude of the form's terms >> fp32 error of either evaluation; the record's
+// cut-off already lies 0.0144 below the exact alpha >= 1/255 threshold), and a sub-block that is skipped would only have added
+// exact zeros: gradients are bit-identical to the unmasked kernel (tests/test_parity_gpu.py::test_backward_subblock_masks...).
+// Max of q(d) = A' dx^2 + B' dx dy + C' dy^2 (A', C' < 0) over a box not containing 0: on one of the four edges, where q is a
+// concave parabola in the free coordinate - clamp its vertex into the edge.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gsr_clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+__device__ __forceinline__ uint32_t gsr_subblock_mask(const float4& r0, const float4& r1, float ox, float oy) {
+  const float As = r0.z, Bs = r0.w, Cs = r1.x, pmin = r1.z;
+  if (!(pmin < 1.0e30f)) return 0u;                        // padding slot: never reached
+  const float kx = -0.5f * Bs * __builtin_amdgcn_rcpf(As), ky = -0.5f * Bs * __builtin_amdgcn_rcpf(Cs);
+  const float aA = fabsf(As), aB = fabsf(Bs), aC = fabsf(Cs);
+  uint32_t m = 0u;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const float dxh = r0.x - (ox + (float)((s & 1) * 8)), dxl = dxh - 7.0f;      // d = mean - pixel over the sub-block's pixels
+    const float dyh = r0.y - (oy + (float)((s >> 1) * 8)), dyl = dyh - 7.0f;
+    auto q = [&](float dx, float dy) { return __builtin_fmaf(Cs * dy, dy, __builtin_fmaf(Bs, dy, As * dx) * dx); };
+    const float e0 = q(dxl, gsr_clampf(ky * dxl, dyl, dyh)), e1 = q(dxh, gsr_clampf(ky * dxh, dyl, dyh));
+    const float e2 = q(gsr_clampf(kx * dyl, dxl, dxh), dyl), e3 = q(gsr_clampf(kx * dyh, dxl, dxh), dyh);
+    const bool inside = dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f;
+    const float qmax = inside ? 0.0f : fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+    const float dxm = fmaxf(fabsf(dxl), fabsf(dxh)), dym = fmaxf(fabsf(dyl), fabsf(dyh));
+    const float mag = aA * dxm * dxm + aB * dxm * dym + aC * dym * dym;
+    if (qmax >= pmin - 2.0e-6f * mag) m |= 1u << s;
+  }
+  return m;
+}
+
 #ifndef BWD1_BATCH
 #define BWD1_BATCH 64
 #endif
-template <bool DEPTH>
-__global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x, const uint2* __restrict__ ranges,
+// MASK = true (round 4, the default): sub-block masks from the staging step (gsr_subblock_mask) replace the per-(entry, sub-block)
+// wave-level reject tests of the loop; MASK = false (GSR_BWD_MASK=0): the round-3 loop, kept for the A/B and the bit-identity test.
+#ifndef BWD_TILE_WAVES
+#define BWD_TILE_WAVES 6   // waves per SIMD the register allocation must admit (80 VGPRs): 8160 one-wave tiles at 1080p want them all
+#endif
+template <bool DEPTH, bool MASK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAVES, 8))) void k_render_bwd_tile(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ point_list,
                                                         const float4* __restrict__ rec, const float* __restrict__ bg,
                                                         const float* __restrict__ final_T,
@@ -508,13 +558,21 @@ __global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x
   for (int b = 0; b < rounds; b++) {
     __syncthreads();   // (one wave: orders this wave's LDS reads of the previous batch before the stores below)
     const int e_idx = toDo - 1 - (b * BWD1_BATCH + lane);   // back-to-front staging
+    uint32_t mymask = 0u;                                    // (MASK) bit s: entry `lane` of this batch can touch sub-block s
     if (e_idx >= 0) {
       const uint32_t id32 = point_list[range.x + e_idx];
       if (id32 != 0xFFFFFFFFu) {
         const size_t id = id32;
-        s0[lane] = rec[3 * id + 0];
-        s1[lane] = rec[3 * id + 1];
+        const float4 r0 = rec[3 * id + 0], r1 = rec[3 * id + 1];
+        s0[lane] = r0;
+        s1[lane] = r1;
         s2[lane] = rec[3 * id + 2];
+        if (MASK) {
+          mymask = gsr_subblock_mask(r0, r1, (float)(tile_x * GSR_TILE), (float)(tile_y * GSR_TILE));
+#pragma unroll
+          for (int s = 0; s < 4; s++)
+            if (e_idx + 1 > sub_last[s]) mymask &= ~(1u << s);   // every pixel of the sub-block finished in front of it
+        }
       } else {
         s0[lane] = z4;
         s1[lane] = make_float4(0.f, 0.f, 3.0e38f, 0.f);
@@ -532,18 +590,35 @@ __global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x
       const float dx0 = a.x - px0, dy0 = a.y - py0;
       float4 c;
       bool have_c = false;
+      const uint32_t emask = MASK ? (uint32_t)__builtin_amdgcn_readlane((int)mymask, j) : 0xFu;   // SGPR
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        if (entry1 > sub_last[s]) continue;            // scalar: every pixel of this sub-block finished earlier
-        const float dx = dx0 - (float)((s & 1) * 8), dy = dy0 - (float)((s >> 1) * 8);
-        const float power = gsr_power2(a, bb, dx, dy);
-        const bool pre = entry1 <= last[s] && power >= bb.z;
-        const uint64_t m_pre = BALLOT(entry1 <= last[s]) & BALLOT(power >= bb.z);
-        if (m_pre == 0ull) continue;
-        const float G = __builtin_amdgcn_exp2f(power);
-        const float alpha = fminf(0.99f, bb.y * G);
-        const bool ok = pre && power <= 0.0f && alpha >= ALPHA_MIN;
-        if ((m_pre & BALLOT(power <= 0.0f) & BALLOT(alpha >= ALPHA_MIN)) == 0ull) continue;
+        float power, G, alpha;
+        bool ok;
+        float dx, dy;
+        if (MASK) {
+          if (!(emask & (1u << s))) continue;          // scalar: the Gaussian cannot reach this sub-block (or nobody is left in it)
+          dx = dx0 - (float)((s & 1) * 8);
+          dy = dy0 - (float)((s >> 1) * 8);
+          power = gsr_power2(a, bb, dx, dy);
+          G = __builtin_amdgcn_exp2f(power);
+          alpha = fminf(0.99f, bb.y * G);
+          // (alpha >= 1/255 implies power >= bb.z: the cut-off lies 0.0144 below the threshold, so this IS the round-3 `ok`)
+          ok = entry1 <= last[s] && power <= 0.0f && alpha >= ALPHA_MIN;
+          if ((BALLOT(entry1 <= last[s]) & BALLOT(power <= 0.0f) & BALLOT(alpha >= ALPHA_MIN)) == 0ull) continue;
+        } else {
+          if (entry1 > sub_last[s]) continue;            // scalar: every pixel of this sub-block finished earlier
+          dx = dx0 - (float)((s & 1) * 8);
+          dy = dy0 - (float)((s >> 1) * 8);
+          power = gsr_power2(a, bb, dx, dy);
+          const bool pre = entry1 <= last[s] && power >= bb.z;
+          const uint64_t m_pre = BALLOT(entry1 <= last[s]) & BALLOT(power >= bb.z);
+          if (m_pre == 0ull) continue;
+          G = __builtin_amdgcn_exp2f(power);
+          alpha = fminf(0.99f, bb.y * G);
+          ok = pre && power <= 0.0f && alpha >= ALPHA_MIN;
+          if ((m_pre & BALLOT(power <= 0.0f) & BALLOT(alpha >= ALPHA_MIN)) == 0ull) continue;
+        }
         if (!have_c) { c = s2v[j]; have_c = true; }
         any = true;
         const float a_e = ok ? alpha : 0.f;
@@ -589,6 +664,8 @@ __global__ __launch_bounds__(64) void k_render_bwd_tile(int W, int H, int grid_x
       }
     }
     __syncthreads();
+    // (the nine sums are zero between entries; saying so here lets their registers go free across the staging code above)
+    acc0 = acc1 = acc2 = acc3 = acc4 = acc5 = acc6 = acc7 = acc8 = acc9 = 0.f;
     // flush the batch: 3 float4 per entry, at the entry's emission slot (grouped per Gaussian for k_preprocess_bwd)
     for (int q = lane; q < n * GSR_IGRAD_F4; q += 64) {
       const int j = q / GSR_IGRAD_F4, part = q - j * GSR_IGRAD_F4;
@@ -620,15 +697,20 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
                            const uint32_t* slot_of_pos, float4* igrad, const uint32_t* n_dev, uint32_t cap, hipStream_t st) {
   // One wave per tile needs enough tiles to keep 1024 SIMDs busy: below ~6 tiles per SIMD (720p: 3600 tiles) the four-waves-per-tile form
   // (same results up to summation order inside a tile) has the shorter critical path.  GSR_BWD_FORM=quad|tile forces one.
-  static const char* form = getenv("GSR_BWD_FORM");
+  const char* form = getenv("GSR_BWD_FORM");          // (read per call: the tests switch forms inside one process)
+  const char* mk = getenv("GSR_BWD_MASK");
   const bool quad = form ? !strcmp(form, "quad") : tiles < 6000;
+  const bool mask = !(mk && !strcmp(mk, "0"));
   if (!quad || (form && !strcmp(form, "tile"))) {
-    if (dL_dinvdepth)
-      GSR_LAUNCH("render_bwd", k_render_bwd_tile<true>, dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height,
-                 grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap);
-    else
-      GSR_LAUNCH("render_bwd", k_render_bwd_tile<false>, dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height,
-                 grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap);
+#define GSR_BWD_TILE_LAUNCH(D, M)                                                                                          \
+  GSR_LAUNCH("render_bwd", (k_render_bwd_tile<D, M>), dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height, grid_x, \
+             ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap)
+    if (dL_dinvdepth) {
+      if (mask) GSR_BWD_TILE_LAUNCH(true, true); else GSR_BWD_TILE_LAUNCH(true, false);
+    } else {
+      if (mask) GSR_BWD_TILE_LAUNCH(false, true); else GSR_BWD_TILE_LAUNCH(false, false);
+    }
+#undef GSR_BWD_TILE_LAUNCH
     return;
   }
   if (dL_dinvdepth)

@@ -38,36 +38,48 @@ class GaussianRasterizationSettings(NamedTuple):
     antialiasing: bool = False
 
 
-# One-shot hand-off used by the view-sharded data-parallel trainer (scene_utils/trainer.py): when set, the NEXT forward runs
-# the geometry stages first, makes the current stream wait for this event (the SH coefficients' all-reduce + Adam update,
-# in flight on another stream), and only then evaluates the colours (gsr_forward_prepare_geometry / gsr_forward_shade).
-_sh_ready_event = None
+class BackwardFold:
+    """Per-call request - and receipt - for work the rasterizer's backward can do in its last kernel.  Pass it to THE forward whose
+    backward is meant (`GaussianRasterizer.forward(..., fold=...)`, `render(..., fold=...)`); it travels on that call's autograd
+    ctx, so any other render / backward in between (a viewer frame, an evaluation view, another device or thread) neither sees
+    nor consumes it (no global state, re-entrant per device).
+
+    optimizer      a FusedAdam / SparseGaussianAdam over the model's six parameter groups (named xyz, f_dc, f_rest, opacity,
+                   scaling, rotation as in reference scene/gaussian_model.py:160-168): the backward of a call that received
+                   exactly those parameters (raw-parameter call form, dc / rest separate) applies the Adam update itself
+                   (gsr_backward_adam) and returns no gradient for them.  `optimizer_taken` says whether it did; if not, the
+                   gradients are in `.grad` as usual and the caller runs optimizer.step().
+    split_rows     (dense Adam only) the rows WITHOUT tile instances in that forward (exact zero gradient) are updated by
+                   gsr_adam_step_culled_rows on a side stream while the compositing backward - bound by VALU issue, the HBM
+                   idle - runs on the caller's stream; bit-identical to the unsplit update.
+    stats          (xyz_gradient_accum [P,1], denom [P,1], max_radii2D [P]): the backward also performs this view's
+                   `add_densification_stats` (reference scene/gaussian_model.py:431-433) and the `max_radii2D` update
+                   (train.py:159) - same arithmetic as gsr_densification_stats, no extra pass, no extra launch (`stats_taken`).
+    skip_sh_rest   (view-sharded exchange "sh_rank1", scene_utils/parallel.py) a call that got `dc` and `shs` separately forms
+                   dL/ddc only and returns None for `shs`: the ranks exchange dL/ddc and rebuild the other coefficients' mean
+                   gradient from it, so this rank's own 180 B per Gaussian are not written at all (`sh_rest_skipped`)."""
+
+    __slots__ = ("optimizer", "split_rows", "stats", "skip_sh_rest", "optimizer_taken", "stats_taken", "sh_rest_skipped")
+
+    def __init__(self, optimizer=None, split_rows=False, stats=None, skip_sh_rest=False):
+        self.optimizer = optimizer
+        self.split_rows = bool(split_rows) and optimizer is not None
+        self.stats = None if stats is None or stats[0] is None else tuple(stats)
+        self.skip_sh_rest = bool(skip_sh_rest)
+        self.optimizer_taken = self.stats_taken = self.sh_rest_skipped = False
 
 
-def defer_sh_until(event):
-    """`event`: a recorded torch.cuda.Event after which `dc` / `shs` hold this step's values (None cancels)."""
-    global _sh_ready_event
-    _sh_ready_event = event
-
-
-# One-shot hand-off from the trainer: fold THIS optimizer's step into the next rasterizer backward (gsr_backward_adam).
-_fused_optimizer = None
-fused_backward_count = 0
-
-
-_split_rows = False
-_side_streams = {}
-_fold_stats = None
-_skip_sh_rest = False
-
-
-_last_dc_grad = None       # (data_ptr, numel) of the dc gradient the most recent backward returned
+_side_streams = {}         # device index -> side stream of the split optimizer update (a cache, not a hand-off)
 GRAD_ARENA_ALIGN = 64      # floats: every gradient tensor of the arena starts on a 256-byte boundary
+GRAD_ARENA_SPARE = 3       # floats left free behind EVERY tensor of the arena (so the layout is a function of the sizes alone:
+#                            scene_utils.parallel.canonical_offsets predicts it on every rank without looking at addresses)
+_SPARE = "_gsr_spare_floats"   # attribute of an arena's STORAGE: {(element offset, numel): spare floats behind} - see dc_grad_tail_row
 
 
 def _grad_arena(dev, parts):
-    """parts: ((shape | None, spare floats behind it), ...) -> one tensor per part (None where the shape is None), all views of
-    ONE float32 allocation, in order, each starting on a GRAD_ARENA_ALIGN boundary."""
+    """parts: ((shape | None, spare floats wanted behind it), ...) -> one tensor per part (None where the shape is None), all
+    views of ONE float32 allocation, in order, each starting on a GRAD_ARENA_ALIGN boundary, each followed by at least
+    GRAD_ARENA_SPARE free floats."""
     offs, total = [], 0
     for shape, spare in parts:
         if shape is None:
@@ -77,57 +89,28 @@ def _grad_arena(dev, parts):
         for d in shape:
             n *= int(d)
         offs.append((total, n))
-        total += -(-(n + spare) // GRAD_ARENA_ALIGN) * GRAD_ARENA_ALIGN
+        total += -(-(n + max(int(spare), GRAD_ARENA_SPARE)) // GRAD_ARENA_ALIGN) * GRAD_ARENA_ALIGN
     flat = torch.empty(total, dtype=torch.float32, device=dev)
+    # what is spare behind which tensor is a property of THIS allocation: it is recorded on the storage object, which stays the
+    # same object when autograd moves the tensor into `.grad` and is a different one for any copy / accumulated sum of it
+    # (plain numbers only: a tensor stored on its own storage would be a reference cycle no collector can see)
+    spares = {o: max(int(spare), GRAD_ARENA_SPARE) for o, (shape, spare) in zip(offs, parts) if o is not None}
+    if spares:
+        setattr(flat.untyped_storage(), _SPARE, spares)
     return [None if o is None else flat[o[0]:o[0] + o[1]].view(shape) for o, (shape, _) in zip(offs, parts)]
 
 
 def dc_grad_tail_row(g):
-    """`g`: a dc gradient ([P, 1, 3]).  If it is the tensor the most recent rasterizer backward returned (not a copy, nothing
-    accumulated into another buffer), the 3 floats behind it are spare: returns the [P + 1, 3] tensor over both (the sh_rank1
-    exchange writes the camera centre into the last row instead of concatenating 12 B per Gaussian), else None."""
-    if _last_dc_grad is None or g is None or not g.is_contiguous() or (g.data_ptr(), g.numel()) != _last_dc_grad:
+    """`g`: a dc gradient ([P, 1, 3]).  If it still IS the tensor a rasterizer backward returned (its storage is that backward's
+    gradient arena - not a copy, not a sum accumulated into another buffer), the 3 floats behind it are spare: returns the
+    [P + 1, 3] tensor over both (the sh_rank1 exchange writes the camera centre into the last row instead of concatenating 12 B
+    per Gaussian), else None.  No process-wide "most recent backward": the knowledge rides on the allocation itself."""
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+        return None
+    spares = getattr(g.untyped_storage(), _SPARE, None)
+    if spares is None or spares.get((g.storage_offset(), g.numel()), 0) < 3 or g.numel() % 3:
         return None
     return torch.empty(0, dtype=g.dtype, device=g.device).set_(g.untyped_storage(), g.storage_offset(), (g.numel() // 3 + 1, 3), (3, 1))
-
-
-def skip_sh_rest_grad_in_next_backward(on=True):
-    """One-shot (view-sharded exchange "sh_rank1", scene_utils/parallel.py): the next rasterizer backward of a call that got `dc`
-    and `shs` separately forms dL/ddc only and returns None for `shs` - the ranks exchange dL/ddc and rebuild the other
-    coefficients' mean gradient from it, so this rank's own 180 B per Gaussian need not be written at all."""
-    global _skip_sh_rest
-    _skip_sh_rest = bool(on)
-
-
-def fold_densification_stats_into_next_backward(xyz_gradient_accum, denom, max_radii2D):
-    """One-shot: the next rasterizer backward also performs this view's `add_densification_stats` (reference
-    scene/gaussian_model.py:431-433) and the `max_radii2D` update (train.py:159) on the given [P,1], [P,1], [P] tensors - same
-    arithmetic as gsr_densification_stats, no extra pass and no extra launch.  None cancels."""
-    global _fold_stats
-    _fold_stats = None if xyz_gradient_accum is None else (xyz_gradient_accum, denom, max_radii2D)
-
-
-def stats_pending():
-    return _fold_stats is not None
-
-
-def fuse_optimizer_into_next_backward(optimizer, split_rows=False):
-    """`optimizer`: a FusedAdam / SparseGaussianAdam over the model's six parameter groups (named xyz, f_dc, f_rest, opacity,
-    scaling, rotation as in reference scene/gaussian_model.py:160-168), or None to cancel.  The next backward of a rasterizer
-    call that received exactly those parameters (raw-parameter call form, dc / rest separate) then applies the Adam update
-    itself and returns no gradient for them; any other backward leaves the hand-off in place, so the caller can check
-    `fuse_pending()` afterwards and fall back to optimizer.step().
-    split_rows (dense Adam only): the rows WITHOUT tile instances in that forward (exact zero gradient) are updated by
-    gsr_adam_step_culled_rows on a side stream while the compositing backward - bound by VALU issue, the HBM idle - runs on
-    the caller's stream; the backward's last kernel then updates the rows with instances.  Bit-identical to the unsplit update;
-    later work on the caller's stream is ordered behind both halves."""
-    global _fused_optimizer, _split_rows
-    _fused_optimizer = optimizer
-    _split_rows = bool(split_rows) and optimizer is not None
-
-
-def fuse_pending():
-    return _fused_optimizer is not None
 
 
 _GROUP_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
@@ -290,7 +273,12 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                raster_settings, raw_activations=False, for_backward=True):
+                raster_settings, raw_activations=False, for_backward=True, fold=None, sh_ready_event=None, forward_mode=None):
+        """fold: a BackwardFold for THIS call's backward (kept on ctx).  sh_ready_event: a recorded torch.cuda.Event after which
+        `dc` / `shs` hold this step's values (the view-sharded trainer's SH all-reduce + Adam update, in flight on another
+        stream): the geometry stages run first, the stream waits for the event and only then evaluates the colours
+        (gsr_forward_prepare_geometry / gsr_forward_shade).  forward_mode: "exact" | "async" | "sync" for this call (default:
+        the process-wide mode, GSR_FORWARD_MODE / set_forward_mode)."""
         lib = _C.lib()
         raw_activations = bool(raw_activations) and cov3D_precomp is None
         if not means3D.is_cuda:
@@ -329,8 +317,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                               raw_activations)
             geom = ws.ensure_geom(lib, P)
             img = ws.ensure_img(lib, W, H)
-            global _sh_ready_event
-            ev, _sh_ready_event = _sh_ready_event, None
+            ev = sh_ready_event
             split = ev is not None and colors_precomp is None
             if ev is not None and not split:
                 torch.cuda.current_stream().wait_event(ev)
@@ -338,7 +325,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             key = (P, W, H)
             stream = _stream()
             try:
-                mode = _ws.forward_mode()
+                mode = _ws.forward_mode() if forward_mode is None else forward_mode
+                if mode not in _ws._MODES:
+                    raise ValueError(f"forward_mode={mode!r}: expected one of {_ws._MODES}")
                 if capturing:
                     if rs.debug or rs.prefiltered or key not in pool.capacity or not pool.status_free:
                         raise _C.GsrError("gsr: a forward under graph capture needs an eager warm-up of the same shape first "
@@ -415,6 +404,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
         ctx.raster_settings = rs
         ctx.raw_activations = raw_activations
+        ctx.fold = fold if needs_grad else None
         ctx.num_rendered = R                 # what the binning state was laid out for (the count itself, or the capacity)
         ctx.has = (dc is not None, sh is not None, colors_precomp is not None, scales is not None,
                    cov3D_precomp is not None)
@@ -448,25 +438,26 @@ class _RasterizeGaussians(torch.autograd.Function):
         def like(t, *shape):
             return torch.empty(*shape, dtype=torch.float32, device=dev) if t is not None else None
 
-        global _fused_optimizer, fused_backward_count, _fold_stats, _skip_sh_rest
+        fold = ctx.fold
         with _C.on_device(dev):
-            stats, _fold_stats = _fold_stats, None
-            skip_rest, _skip_sh_rest = _skip_sh_rest and dc is not None and sh is not None and colors_precomp is None, False
+            stats = fold.stats if (fold is not None and not fold.stats_taken) else None    # (once per request)
+            skip_rest = fold is not None and fold.skip_sh_rest and dc is not None and sh is not None and colors_precomp is None
             if stats is not None and (stats[0].shape[0] != P or not all(t.is_contiguous() and t.dtype == torch.float32
                                                                         for t in stats)):
                 raise _C.GsrError("fold_densification_stats: statistics tensors do not match this forward's Gaussians")
-            fused, split = None, False
-            if P > 0 and _fused_optimizer is not None and ctx.raw_activations and dc is not None and colors_precomp is None:
-                split = _split_rows and not isinstance(_fused_optimizer, SparseGaussianAdam)
+            fused, split, opt = None, False, (fold.optimizer if fold is not None else None)
+            if P > 0 and opt is not None and not fold.optimizer_taken and ctx.raw_activations and dc is not None \
+                    and colors_precomp is None:
+                split = fold.split_rows and not isinstance(opt, SparseGaussianAdam)
                 # factors kept in device memory (enable_dynamic_hyperparameters): an eager backward stores this step's values
                 # in front of its kernels; under graph capture nothing is counted or stored - whoever replays the graph does
                 # both per replay (push_dynamic_hyperparameters)
-                dynamic = getattr(_fused_optimizer, "_gsr_dynamic", None) is not None
+                dynamic = getattr(opt, "_gsr_dynamic", None) is not None
                 capturing = dynamic and torch.cuda.is_current_stream_capturing()
-                fused = _fused_adam_struct(_fused_optimizer, (means3D, dc, sh, opacities, scales, rotations),
+                fused = _fused_adam_struct(opt, (means3D, dc, sh, opacities, scales, rotations),
                                            rows="with_instances" if split else None, advance=not capturing)
                 if fused is not None and dynamic and not capturing:
-                    _C.check(lib.gsr_adam_set_dynamic(C.byref(fused[0]), _C.ptr(_fused_optimizer._gsr_dynamic), _stream()))
+                    _C.check(lib.gsr_adam_set_dynamic(C.byref(fused[0]), _C.ptr(opt._gsr_dynamic), _stream()))
             d_means2D = torch.empty(P, 3, dtype=torch.float32, device=dev)
             if fused is None and P > 0:
                 # ONE allocation for the gradients, geometry first: a data-parallel caller can exchange the four geometry tensors
@@ -478,8 +469,6 @@ class _RasterizeGaussians(torch.autograd.Function):
                     (tuple(dc.shape) if dc is not None else None, 3),
                     (tuple(sh.shape) if sh is not None and not skip_rest else None, 0),
                     ((P, 3) if colors_precomp is not None else None, 0), ((P, 6) if cov3D_precomp is not None else None, 0)))
-                global _last_dc_grad
-                _last_dc_grad = (d_dc.data_ptr(), d_dc.numel()) if d_dc is not None else None
             elif fused is None:
                 d_means3D = torch.empty(P, 3, dtype=torch.float32, device=dev)
                 d_opac = torch.empty(opacities.shape if opacities is not None else (P, 1), dtype=torch.float32, device=dev)
@@ -504,8 +493,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                                     (stats if stats is not None else (None, None, None))])
                 try:
                     if fused is not None:
-                        _fused_optimizer = None
-                        fused_backward_count += 1
+                        fold.optimizer_taken = True          # (a second backward through a retained graph must not step again)
+                        pool = _ws.pool(dev)
+                        pool.stats["folded_backwards"] = pool.stats.get("folded_backwards", 0) + 1
                         if split:
                             # the culled rows' half: needs only the forward's state, so it runs beside the compositing backward
                             side = _side_streams.get(dev.index)
@@ -531,17 +521,21 @@ class _RasterizeGaussians(torch.autograd.Function):
                               cov3D_precomp, grad_color, grad_invdepth, radii)
                     raise
                 ws.stream = cur
-        return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None, None)
+            if fold is not None:
+                fold.stats_taken = fold.stats_taken or stats is not None      # (P == 0: no rows, nothing to add)
+                fold.sh_rest_skipped = bool(skip_rest)
+        return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None, None, None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, raw_activations=False):
+                        raster_settings, raw_activations=False, fold=None, sh_ready_event=None, forward_mode=None):
     # forward-only render (torch.no_grad(), reference render.py:49, or no input that requires grad): the library then skips
     # what only a backward would need
     tensors = (means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
     for_backward = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
     return _RasterizeGaussians.apply(means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, raw_activations, for_backward)
+                                     cov3Ds_precomp, raster_settings, raw_activations, for_backward, fold, sh_ready_event,
+                                     forward_mode)
 
 
 def pair_evaluations(raster_settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
@@ -599,10 +593,12 @@ class GaussianRasterizer(nn.Module):
             return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, dc=None, raw_activations=False):
-        """Arguments of the reference's call (gaussian_renderer/__init__.py:90-109).  `raw_activations=True` (an extension,
-        keyword only in spirit): `opacities`, `scales`, `rotations` are the model's RAW parameters; sigmoid / exp / normalize
-        are applied inside the projection kernel and the returned gradients are w.r.t. the raw parameters."""
+                cov3D_precomp=None, dc=None, raw_activations=False, *, fold=None, sh_ready_event=None, forward_mode=None):
+        """Arguments of the reference's call (gaussian_renderer/__init__.py:90-109).  Extensions, all optional and all PER CALL
+        (nothing is armed process-wide): `raw_activations=True`: `opacities`, `scales`, `rotations` are the model's RAW
+        parameters; sigmoid / exp / normalize are applied inside the projection kernel and the returned gradients are w.r.t. the
+        raw parameters.  `fold`: a BackwardFold (optimizer step / densification statistics / skipped dL/dsh_rest in this call's
+        backward).  `sh_ready_event`: colours wait for this event.  `forward_mode`: "exact" | "async" | "sync" for this call."""
         def none_if_empty(t):
             return None if (t is None or t.numel() == 0) else t
         shs, colors_precomp, dc = none_if_empty(shs), none_if_empty(colors_precomp), none_if_empty(dc)
@@ -616,7 +612,7 @@ class GaussianRasterizer(nn.Module):
                     ((scales is not None or rotations is not None) and cov3D_precomp is not None):
                 raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         return rasterize_gaussians(means3D, means2D, dc, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, self.raster_settings, raw_activations)
+                                   cov3D_precomp, self.raster_settings, raw_activations, fold, sh_ready_event, forward_mode)
 
 
 from .sparse_adam import SparseGaussianAdam, FusedAdam  # noqa: E402,F401   (reference train.py:37-41)

@@ -63,7 +63,9 @@ def _screenspace_zeros(like):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, separate_sh=False,
-           override_color=None, use_trained_exp=False):
+           override_color=None, use_trained_exp=False, **rasterizer_kw):
+    """`rasterizer_kw`: per-call extensions of this rasterizer, forwarded to `GaussianRasterizer.forward` (`fold`, `sh_ready_event`,
+    `forward_mode`); none given = the reference's call forms, unchanged."""
     # zero tensor that receives the screen-space (NDC) gradient of the 2-D means (reference :26-30)
     # (a leaf here: its .grad is what the callers read; the reference's `+ 0` / retain_grad() pair gives the same .grad at
     # the price of one more launch per step)
@@ -125,11 +127,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if separate_sh:
         rendered_image, radii, depth_image = rasterizer(
             means3D=means3D, means2D=means2D, dc=dc, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_activations": True} if use_raw else {}))
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_activations": True} if use_raw else {}),
+            **rasterizer_kw)
     else:
         rendered_image, radii, depth_image = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_activations": True} if use_raw else {}))
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_activations": True} if use_raw else {}),
+            **rasterizer_kw)
 
     if use_trained_exp:
         exposure = pc.get_exposure_from_name(viewpoint_camera.image_name)

@@ -2,7 +2,7 @@
 
 The reference is single-GPU (utils/general_utils.py:133 pins cuda:0; no collective anywhere).  Views are
 independent units: every rank holds the full Gaussian set, renders views {v : v mod world == rank} and the six
-leaf gradients (59 floats per Gaussian at SH degree 3) are averaged in place by back-to-back all-reduces per step
+leaf gradients (59 floats per Gaussian at SH degree 3) are averaged in place, as ONE flat span per exchange
 (RCCL over xGMI when the backend is "nccl").  Densification statistics are
 per-view quantities and are reduced separately (`reduce_densification_stats`).
 """
@@ -38,79 +38,85 @@ def shard_views(n_views: int, rank: int, world: int, epoch_perm=None):
     return ids[rank::world]
 
 
-def _nothing_to_exchange(world: int) -> bool:
-    """One rank and no process group.  (One rank WITH a group - the single-GPU rehearsal of the N > 1 schedule, Trainer
-    single_rank_group - runs the collectives: a mean over one rank.)"""
-    return world <= 1 and not (dist.is_available() and dist.is_initialized())
+ARENA_ALIGN = 64      # floats; = diff_gaussian_rasterization.GRAD_ARENA_ALIGN (asserted by tests/test_distributed_cpu.py)
+ARENA_SPARE = 3       # floats kept free behind every tensor of an arena (the sh_rank1 exchange's camera-centre row)
 
 
-def adjacent_spans(tensors, max_gap=256):
-    """Contiguous tensors that lie in ONE storage with gaps of at most `max_gap` elements between them (the rasterizer's
-    backward returns its gradients that way: diff_gaussian_rasterization._grad_arena), grouped into flat 1-D tensors over
-    [first start, last end): one collective per span instead of one per tensor.  -> [(flat, [tensors of the span])]; a tensor
-    that shares nothing is its own span (flat = its own flattened view).  (The gaps travel too: alignment padding, never read.)
-    The ORDER of the spans depends only on the order of `tensors` and on their offsets inside a storage - never on addresses -
-    so every rank issues its collectives in the same order."""
-    groups = {}                                    # storage -> indices, in order of first appearance
-    for i, t in enumerate(tensors):
-        groups.setdefault(t.untyped_storage().data_ptr(), []).append(i)
-    out = []
-    for idx in groups.values():
-        idx.sort(key=lambda i: tensors[i].storage_offset())
-        run = [tensors[idx[0]]]
-        for i in idx[1:] + [None]:
-            t = tensors[i] if i is not None else None
-            end = run[-1].storage_offset() + run[-1].numel()
-            if t is not None and t.dtype == run[0].dtype and 0 <= t.storage_offset() - end <= max_gap:
-                run.append(t)
-                continue
-            if len(run) == 1:
-                out.append((run[0].view(-1), run))
-            else:
-                start = run[0].storage_offset()
-                flat = torch.empty(0, dtype=run[0].dtype, device=run[0].device).set_(run[0].untyped_storage(), start,
-                                                                                     (end - start,), (1,))
-                out.append((flat, run))
-            run = [t]
-    return out
+def canonical_offsets(numels):
+    """Element offsets of tensors with `numels` elements laid out side by side the way the rasterizer's backward lays out its
+    gradient arena (diff_gaussian_rasterization._grad_arena): in list order, ARENA_SPARE floats free behind each, each start on
+    an ARENA_ALIGN boundary.  -> (offsets, total span length = last offset + last numel).  A function of the SIZES only, so
+    every rank computes the same plan."""
+    offs, cur = [], 0
+    for n in numels:
+        offs.append(cur)
+        cur += -(-(int(n) + ARENA_SPARE) // ARENA_ALIGN) * ARENA_ALIGN
+    return offs, (offs[-1] + int(numels[-1]) if offs else 0)
+
+
+def flat_span(tensors):
+    """ONE flat tensor (the tensors' common dtype) of canonical_offsets' length over `tensors` (in list order).  If they already sit at exactly those
+    offsets in one storage (the rasterizer's gradient arena does that), the span is a view of it - (flat, None); otherwise a
+    zero-filled scratch buffer with the tensors copied in - (flat, [views to copy back from]).  Either way the collective that
+    travels is the same size on every rank: the plan never depends on a rank's local memory layout."""
+    offs, total = canonical_offsets([t.numel() for t in tensors])
+    t0 = tensors[0]
+    base = t0.storage_offset()
+    same = all(t.dtype == t0.dtype and t.is_contiguous() and t.device == t0.device and
+               t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() and t.storage_offset() - base == o
+               for t, o in zip(tensors, offs))
+    if same and (base + total) * t0.element_size() <= t0.untyped_storage().nbytes():
+        flat = torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage(), base, (total,), (1,))
+        return flat, None
+    flat = torch.zeros(total, dtype=t0.dtype, device=t0.device)
+    views = [flat[o:o + t.numel()].view(t.shape) for t, o in zip(tensors, offs)]
+    for v, t in zip(views, tensors):
+        v.copy_(t)
+    return flat, views
 
 
 class GradBucket:
     """Sums the gradients of `params` over ranks and leaves the MEAN in `.grad`.
 
-    The six leaf gradients are reduced IN PLACE, one collective each, issued back-to-back as async work (RCCL runs
-    them in order on its own stream; the small ones pipeline behind the 180 MB SH-rest tensor).  Flattening them into
-    one buffer would add a 236 MB copy-in and copy-out per step (~0.25 ms on MI355X, ~7 % of the step) for nothing:
-    the collective is bandwidth-bound on the xGMI links either way."""
+    One call = ONE collective over one flat span that holds the gradients side by side in the canonical arena layout
+    (`canonical_offsets`: a function of the tensor sizes and their order only, hence identical on every rank).  The rasterizer's
+    backward returns its gradients in exactly that layout (one allocation, geometry first), so on the training path the span
+    is a view and nothing is copied; a rank whose gradients live elsewhere (a `.grad` autograd cloned, zeros for a missing
+    gradient, gradients that came through torch activations) copies them into a scratch span and back - a local cost that never
+    changes the number or the size of the collectives its peers see.  Pass the parameters in the arena's order (xyz, opacity,
+    scaling, rotation, f_dc, f_rest) for the zero-copy path.  (The ARENA_SPARE / alignment floats between the tensors travel
+    too; nothing reads them.)"""
 
     def __init__(self, params):
         self.params = list(params)
+        self.copied_spans = 0        # calls whose span had to be assembled by copies (diagnostic)
 
-    def all_reduce_mean(self, world: int, group=None, params=None, visible=None):
-        """`params`: optional subset of the bucket's parameters to exchange in this call.
-        `visible` (bool[P], this rank's visibility filter): exchange only the rows some rank saw (`all_reduce_visible_rows`)."""
-        if _nothing_to_exchange(world):
+    def all_reduce_mean(self, world: int, group=None, params=None, visible=None, force=False):
+        """`params`: optional subset of the bucket's parameters to exchange in this call (in the arena's order).
+        `visible` (bool[P], this rank's visibility filter): exchange only the rows some rank saw (`all_reduce_visible_rows`).
+        `force`: run the collectives although world == 1 (the one-rank RCCL rehearsal, Trainer(single_rank_group=True))."""
+        if world <= 1 and not force:
             return
         if visible is not None:
             return self.all_reduce_visible_rows(world, visible, group=group, params=params)
         backend = dist.get_backend(group)
         use_avg = backend == "nccl"                  # RCCL averages in the reduction; gloo has no AVG
-        todo = self.params if params is None else list(params)
+        todo = [p for p in (self.params if params is None else list(params)) if p.numel() > 0]
+        if not todo:
+            return
         for p in todo:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-            if not p.grad.is_contiguous():
-                p.grad = p.grad.contiguous()
-        # gradients that sit side by side in one allocation (the rasterizer's backward returns them so) go as ONE collective
-        spans = adjacent_spans([p.grad for p in todo])
-        works = [dist.all_reduce(flat, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, group=group, async_op=True)
-                 for flat, _ in spans]
-        for w in works:
-            w.wait()
+            if not p.grad.is_contiguous() or p.grad.dtype != p.dtype:
+                p.grad = p.grad.contiguous().to(p.dtype)
+        flat, views = flat_span([p.grad for p in todo])
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, group=group)
         if not use_avg:
-            for flat, _ in spans:
-                flat.mul_(1.0 / world)
-
+            flat.mul_(1.0 / world)
+        if views is not None:
+            self.copied_spans += 1
+            for p, v in zip(todo, views):
+                p.grad.copy_(v)
 
     def all_reduce_visible_rows(self, world: int, visible, group=None, params=None):
         """Visible-rows-only exchange: a Gaussian culled on EVERY rank has an exactly zero gradient everywhere (the rasterizer
@@ -331,9 +337,11 @@ class ShardedStep:
                    if k in ("exp_avg", "exp_avg_sq"))
 
 
-def reduce_densification_stats(xyz_gradient_accum, denom, max_radii2D, world: int, group=None):
-    """Per-view statistics (reference scene/gaussian_model.py:431-433, train.py:159) -> identical on all ranks."""
-    if _nothing_to_exchange(world):
+def reduce_densification_stats(xyz_gradient_accum, denom, max_radii2D, world: int, group=None, force=False):
+    """Per-view statistics (reference scene/gaussian_model.py:431-433, train.py:159) -> identical on all ranks.
+    world <= 1: nothing to do, whatever process groups exist (independent replicas under one launcher stay independent);
+    `force` runs the collectives anyway (the one-rank rehearsal)."""
+    if world <= 1 and not force:
         return
     dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=group)

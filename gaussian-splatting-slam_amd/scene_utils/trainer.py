@@ -51,7 +51,9 @@ class Trainer:
             raise ValueError("loss: 'hip' or a callable (the pure-PyTorch loss is test infrastructure: oracle/loss_oracle.py)")
         self.loss_fn = loss if callable(loss) else training_loss_fused
         self._loss_arg = loss
-        self.bucket = GradBucket(model.parameters()) if self.distributed else None
+        # (an initialised process group alone changes nothing: only `single_rank_group` makes a one-rank trainer run collectives)
+        self._force_collectives = bool(single_rank_group) and world <= 1
+        self.bucket = GradBucket(self._arena_order_params()) if self.distributed else None
         # N > 1 gradient exchange: "allreduce" (one all-reduce per leaf, every rank runs the whole update),
         # "visible_rows" (the same, restricted to the rows some rank saw), "sharded" (reduce-scatter -> Adam on a 1/N row shard
         # -> all-gather of the parameters; dense optimizers, no densification yet: the moments live per shard)
@@ -97,6 +99,12 @@ class Trainer:
         self._graph = None
         self.rerun_views = 0             # ... and how many truncated frames were run again
 
+    def _arena_order_params(self):
+        """The six leaves in the order the rasterizer's backward lays their gradients out (geometry first): GradBucket's span over
+        them is then a view of that allocation, no copy."""
+        m = self.model
+        return [m._xyz, m._opacity, m._scaling, m._rotation, m._features_dc, m._features_rest]
+
     # statistics live in the model (reference: GaussianModel.xyz_gradient_accum / denom / max_radii2D)
     @property
     def xyz_gradient_accum(self):
@@ -118,14 +126,51 @@ class Trainer:
                             reset=opacity_reset_interval, thr=grad_threshold, min_opacity=min_opacity, seed=seed,
                             max_gaussians=max_gaussians)
 
-    def step(self, view_idx):
+    def step(self, view_idx, forward_mode=None):
         """One optimizer step.  `view_idx`: one view (the reference's batch-1 step) or a list of views whose gradients are
-        accumulated locally before the single cross-rank exchange and the single Adam step (gradient accumulation)."""
+        accumulated locally before the single cross-rank exchange and the single Adam step (gradient accumulation).
+        `forward_mode`: the rasterizer's forward mode for this step's renders (default: the process-wide one)."""
         views = list(view_idx) if isinstance(view_idx, (list, tuple)) else [view_idx]
-        if self.graph_replay and len(views) == 1 and self._graph_step(views[0]):
+        if self.graph_replay and forward_mode is None and len(views) == 1 and self._graph_step(views[0]):
             return self.last
-        unverified = self.model.get_xyz.is_cuda and self._unverified_mode()
-        if unverified:
+        return self._eager_step(views, forward_mode)
+
+    def _render_kwargs(self, n_views, mode, unverified):
+        """Per-call extensions handed to render() on the HIP device (all state of a step's hand-offs lives in these objects and on
+        the autograd ctx of the call they are given to - nothing is armed process-wide): -> (kwargs, BackwardFold | None, whether
+        the optimizer step was asked to ride in the backward)."""
+        if not self.model.get_xyz.is_cuda:
+            return {}, None, False        # (the CPU tests inject the oracle as renderer: the reference's plain call form)
+        import diff_gaussian_rasterization as dgr
+        m = self.model
+        due = self._densify_due(self.iteration + 1)
+        want_fold = self.fuse_step and not self.distributed and n_views == 1 and not due and self.separate_sh
+        # exchange "sh_rank1" with the dense HIP Adam: this rank's dL/df_rest is not exchanged (rebuilt from the ranks' dL/df_dc)
+        # and, unless a densification sits between backward and step, the two SH groups' Adam step rides in the rebuilding
+        # kernel: the backward need not write those 180 B per Gaussian at all
+        self._rank1_fused = (self.rank1_fuse_adam and self.exchange == "sh_rank1" and self.distributed and n_views == 1 and
+                             self.optimizer_kind == "hip" and self.separate_sh and not due)
+        # this view's densification statistics ride in the rasterizer's backward (one pass and one launch less)
+        fold = dgr.BackwardFold(optimizer=self.optimizer if want_fold else None, split_rows=self.split_rows,
+                                stats=(m.xyz_gradient_accum, m.denom, m.max_radii2D), skip_sh_rest=self._rank1_fused)
+        kw = {"fold": fold}
+        if mode == "async" and not unverified:
+            kw["forward_mode"] = "exact"          # this step's frames are verified although the process default is not
+        elif mode is not None and mode != dgr.forward_mode():
+            kw["forward_mode"] = mode
+        ev = getattr(self, "_pending_sh_event", None)
+        if ev is not None:                        # the previous step's SH update is still in flight on the side stream
+            kw["sh_ready_event"] = ev
+        return kw, fold, want_fold
+
+    def _eager_step(self, views, forward_mode=None):
+        is_hip = self.model.get_xyz.is_cuda
+        mode = None
+        unverified = False
+        if is_hip:
+            import diff_gaussian_rasterization as dgr
+            mode = forward_mode if forward_mode is not None else dgr.forward_mode()
+        if mode == "async":
             # the status of the previous step's frame is waited for HERE (it left the device when that frame's compositing kernel
             # started, i.e. long ago unless the host runs more than a step ahead): a truncated frame is run again before the
             # next view is touched, so the updates keep the order of the default mode
@@ -136,19 +181,14 @@ class Trainer:
             # due, several views, N > 1 - verifies its frames like the default mode does.
             unverified = (self.fuse_step and not self.distributed and len(views) == 1 and self.separate_sh
                           and not self._densify_due(self.iteration + 1) and not getattr(self, "_fold_refused", False))
-        exact_here = self.model.get_xyz.is_cuda and self._unverified_mode() and not unverified
+        self._rank1_fused = False
         for n, v in enumerate(views):
             cam = self.cameras[v]
-            if exact_here:
-                import diff_gaussian_rasterization as dgr
-                dgr.set_forward_mode("exact")
-            try:
-                pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh)
-            finally:
-                if exact_here:
-                    dgr.set_forward_mode("async")
+            kw, fold, want_fold = self._render_kwargs(len(views), mode, unverified)
+            pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh, **kw)
+            if "sh_ready_event" in kw:
+                self._pending_sh_event = None     # (that forward made its stream wait for it)
             if unverified:
-                import diff_gaussian_rasterization as dgr
                 self._ticket_view[dgr.last_ticket(self.model.get_xyz.device)] = v
             image, vsp, radii = pkg["render"], pkg["viewspace_points"], pkg["radii"]
             vis = _LazyVisibility(pkg)       # `radii > 0`: only materialised by the branches that use it
@@ -161,53 +201,23 @@ class Trainer:
                     loss = loss + self.depth_weight * torch.abs(pkg["depth"] - self.depth_targets[v]).mean()
             if len(views) > 1:
                 loss = loss / len(views)
-            # this view's densification statistics ride in the rasterizer's backward (one pass and one launch less); any
-            # renderer that does not take the hand-off (the CPU oracle in the gloo tests) leaves it pending -> plain call below
-            fold_stats = self.model.get_xyz.is_cuda
-            if fold_stats:
-                import diff_gaussian_rasterization as dgr
-                dgr.fold_densification_stats_into_next_backward(self.model.xyz_gradient_accum, self.model.denom,
-                                                                self.model.max_radii2D)
-            fold = self.fuse_step and not self.distributed and len(views) == 1 and not self._densify_due(self.iteration + 1) \
-                and self.separate_sh
-            if fold:
-                import diff_gaussian_rasterization as dgr
-                dgr.fuse_optimizer_into_next_backward(self.optimizer, split_rows=self.split_rows)
-            # exchange "sh_rank1" with the dense HIP Adam: this rank's dL/df_rest is not exchanged (rebuilt from the ranks' dL/df_dc)
-            # and, unless a densification sits between backward and step, the two SH groups' Adam step rides in the rebuilding
-            # kernel: the backward need not write those 180 B per Gaussian at all
-            self._rank1_fused = (self.rank1_fuse_adam and self.exchange == "sh_rank1" and self.distributed and len(views) == 1 and
-                                 self.optimizer_kind == "hip" and self.separate_sh and self.model.get_xyz.is_cuda and
-                                 not self._densify_due(self.iteration + 1))
-            if self._rank1_fused:
-                import diff_gaussian_rasterization as dgr
-                dgr.skip_sh_rest_grad_in_next_backward()
             if self._one is None or self._one.device != loss.device:
                 self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
             loss.backward(gradient=self._one)          # .grad accumulates; (a cached seed: no fill launch per step)
-            if self._rank1_fused:
-                dgr.skip_sh_rest_grad_in_next_backward(False)     # (a renderer that did not take the hand-off leaves it set)
-            folded = False
-            if fold:
-                folded = not dgr.fuse_pending()
-                if not folded and unverified:
-                    # the renderer did not take the optimizer (a model wrapper without raw parameters ...): this frame ran
-                    # unverified and its update is about to happen as a launch of its own - look at its status NOW, and from
-                    # here on verify every frame
-                    self._fold_refused = True
-                    t = dgr.last_ticket(self.model.get_xyz.device)
-                    if t in dgr.take_overflowed(self.model.get_xyz.device, wait=True):
-                        self._ticket_view.pop(t, None)
-                        dgr.fuse_optimizer_into_next_backward(None)
-                        dgr.fold_densification_stats_into_next_backward(None, None, None)
-                        self.optimizer.zero_grad(set_to_none=True)
-                        return self.step(view_idx)          # (truncated: zero gradients, nothing applied yet - once more, verified)
-                if not folded:
-                    dgr.fuse_optimizer_into_next_backward(None)     # the rasterizer could not take it: plain step below
-            if fold_stats and dgr.stats_pending():
-                dgr.fold_densification_stats_into_next_backward(None, None, None)
-                fold_stats = False
-            if not fold_stats:
+            # what the backward took of the request (a renderer that does not hand `fold` to the rasterizer - a model wrapper
+            # without raw parameters, the python-SH branch ... - leaves everything False: plain calls below)
+            folded = fold is not None and fold.optimizer_taken
+            self._rank1_fused = self._rank1_fused and fold is not None and fold.sh_rest_skipped
+            if want_fold and not folded and unverified:
+                # this frame ran unverified and its update is about to happen as a launch of its own - look at its status NOW,
+                # and from here on verify every frame
+                self._fold_refused = True
+                t = dgr.last_ticket(self.model.get_xyz.device)
+                if t in dgr.take_overflowed(self.model.get_xyz.device, wait=True):
+                    self._ticket_view.pop(t, None)
+                    self.optimizer.zero_grad(set_to_none=True)
+                    return self._eager_step(views, forward_mode)    # (truncated: zero gradients, nothing applied yet - once more, verified)
+            if fold is None or not fold.stats_taken:
                 with torch.no_grad():
                     # densification statistics are per-view: norm BEFORE any cross-rank reduction
                     self.model.add_densification_stats(vsp, vis.get(), radii)                # train.py:159-160
@@ -240,16 +250,20 @@ class Trainer:
         with torch.no_grad():
             if self.bucket is not None and rank1_cam is not None:
                 m = self.model
-                self.bucket.all_reduce_mean(self.world, params=[m._xyz, m._opacity, m._scaling, m._rotation])
+                self.bucket.all_reduce_mean(self.world, params=[m._xyz, m._opacity, m._scaling, m._rotation],
+                                            force=self._force_collectives)
                 rank1_sh_exchange(m._xyz, m._features_dc, m._features_rest, rank1_cam, m.active_sh_degree, self.world,
                                   optimizer=self.optimizer if self._rank1_fused else None)
             elif self.bucket is not None:
-                self.bucket.all_reduce_mean(self.world, visible=vis.get() if self.exchange == "visible_rows" else None)
+                self.bucket.all_reduce_mean(self.world, visible=vis.get() if self.exchange == "visible_rows" else None,
+                                            force=self._force_collectives)
             if self.densify is not None:
                 # the reference densifies between backward and the optimizer step (train.py:155-168 before :170): the
                 # replaced Parameters carry no gradient, so the step that follows skips them, exactly like there
                 self._maybe_densify(radii)
-            if self.optimizer_kind == "hip_sparse":
+            if folded:
+                pass                     # (densification schedule active but not due: the backward already applied the step)
+            elif self.optimizer_kind == "hip_sparse":
                 self.optimizer.step(vis.get(), radii.shape[0])                                 # train.py:173-175
             else:
                 self.optimizer.step()
@@ -258,6 +272,7 @@ class Trainer:
 
     @staticmethod
     def _unverified_mode():
+        """The process-wide forward mode is "async" (steps may run unverified frames; see _eager_step)."""
         import diff_gaussian_rasterization as dgr
         return dgr.forward_mode() == "async"
 
@@ -279,11 +294,7 @@ class Trainer:
                         st["step"] -= 1
             self.iteration -= 1              # ... and neither may the iteration count (densification / reset schedule)
             self.rerun_views += 1
-            dgr.set_forward_mode("exact")
-            try:
-                self.step(v)
-            finally:
-                dgr.set_forward_mode("async")
+            self._eager_step([v], forward_mode="exact")
         if len(self._ticket_view) > 256:      # statuses arrive in order: anything older than the newest 64 is long verified
             for t in sorted(self._ticket_view)[:-64]:
                 del self._ticket_view[t]
@@ -305,7 +316,6 @@ class Trainer:
         48 of the 59 floats per Gaussian) are all-reduced and applied on a side stream; the main stream exchanges and applies
         the geometry gradients (11 floats) and goes straight on to the next step, whose rasterizer runs projection, depth
         sort, emission and tile sort before it waits for the SH update (diff_gaussian_rasterization.defer_sh_until)."""
-        import diff_gaussian_rasterization as dgr
         m = self.model
         geo, geo_names = [m._xyz, m._opacity, m._scaling, m._rotation], ("xyz", "opacity", "scaling", "rotation")
         sh, sh_names = [m._features_dc, m._features_rest], ("f_dc", "f_rest")
@@ -313,7 +323,7 @@ class Trainer:
         # Collectives of one communicator run in ISSUE order (RCCL keeps one internal stream per communicator): the small
         # geometry exchange goes first so that the main stream only ever waits for it; the SH exchange queues behind it.
         if self.bucket is not None:
-            self.bucket.all_reduce_mean(self.world, params=geo)
+            self.bucket.all_reduce_mean(self.world, params=geo, force=self._force_collectives)
         side.wait_stream(main)                                   # gradients complete (and the geometry exchange issued)
         with torch.cuda.stream(side):
             for p in sh:
@@ -333,7 +343,7 @@ class Trainer:
                 if stepped:
                     sh_names = ()                     # the rebuilding kernel applied the SH groups' step itself
             elif self.bucket is not None:
-                self.bucket.all_reduce_mean(self.world, params=sh)
+                self.bucket.all_reduce_mean(self.world, params=sh, force=self._force_collectives)
             if not sh_names:
                 pass
             elif self.optimizer_kind == "hip_sparse":
@@ -346,7 +356,8 @@ class Trainer:
             self.optimizer.step(vis, radii.shape[0], only=geo_names)
         else:
             self.optimizer.step(only=geo_names)
-        dgr.defer_sh_until(ev)                                   # consumed by the next rasterizer forward
+        # handed to this trainer's NEXT render as `sh_ready_event` (per call: a render of somebody else in between - a viewer,
+        # an evaluation - is not touched by it and must call finish() before it reads the SH parameters)
         self._pending_sh_event = ev
         self.optimizer.zero_grad(set_to_none=True)
 
@@ -365,6 +376,8 @@ class Trainer:
                        and self._gt_is_hip_loss()):
             raise ValueError("graph replay needs one rank, a *_fused optimizer, separate_sh and the HIP loss on the HIP device")
         self.graph_replay, self._graph_warmup = bool(on), int(warmup)
+        if on:
+            self.optimizer.init_state()      # the moments' addresses are part of a captured step's signature: create them now
         self._graph, self._graph_sig, self._graph_warm = None, None, {}
         self.graph_stats = dict(captures=0, replays=0, eager_steps=0, overflow_reruns=0)
 
@@ -372,9 +385,28 @@ class Trainer:
         return self.loss_fn is training_loss_fused
 
     def _graph_signature(self, cam):
+        """Everything a captured step has baked into its launch arguments: shapes, the camera's intrinsics, the scalars of the
+        loss, and the ADDRESS of every tensor the graph reads or writes in place - all six parameters, both Adam moments of
+        each, the three statistics tensors.  (reset_opacity replaces `_opacity` and its moments and nothing else; a densification
+        replaces everything: either way the signature changes and the stale graph is never replayed - ADVICE r3.)"""
         m = self.model
+        ptrs = []
+        for p in m.parameters():
+            st = self.optimizer.state.get(p, {})
+            ptrs += [p.data_ptr(), st["exp_avg"].data_ptr() if "exp_avg" in st else 0,
+                     st["exp_avg_sq"].data_ptr() if "exp_avg_sq" in st else 0]
+        ptrs += [m.xyz_gradient_accum.data_ptr(), m.denom.data_ptr(), m.max_radii2D.data_ptr()]
+        has_depth = self.depth_weight > 0 and self.depth_targets is not None
         return (int(m.get_xyz.shape[0]), int(m.active_sh_degree), int(cam.image_height), int(cam.image_width),
-                float(cam.FoVx), float(cam.FoVy), m._xyz.data_ptr(), m._features_rest.data_ptr())
+                float(cam.FoVx), float(cam.FoVy), float(self.lambda_dssim), float(self.depth_weight) if has_depth else 0.0,
+                self.bg.data_ptr(),
+                *ptrs)
+
+    def _drop_graph(self):
+        """The model's tensors were replaced (densification, pruning, opacity reset): the captured step points at the old ones."""
+        if getattr(self, "_graph", None) is not None:
+            self._graph_settle()
+        self._graph = self._graph_sig = None
 
     def _graph_step(self, v):
         """-> True if the step was done by a replay (or its eager stand-in), False: let the eager path do it."""
@@ -424,19 +456,15 @@ class Trainer:
         dgr.prepare_for_graph_capture(dev)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
+        fold = dgr.BackwardFold(optimizer=self.optimizer, stats=(m.xyz_gradient_accum, m.denom, m.max_radii2D))
         with torch.cuda.graph(graph):
-            pkg = self.render_fn(cam_s, m, self.pipe, self.bg, separate_sh=True)
+            pkg = self.render_fn(cam_s, m, self.pipe, self.bg, separate_sh=True, fold=fold)
             loss = self.loss_fn(pkg["render"], gt, self.lambda_dssim)
             if depth is not None:
                 from fused_ssim import l1_mean_loss
                 loss = loss + l1_mean_loss(pkg["depth"], depth, self.depth_weight)
-            dgr.fold_densification_stats_into_next_backward(m.xyz_gradient_accum, m.denom, m.max_radii2D)
-            dgr.fuse_optimizer_into_next_backward(self.optimizer, split_rows=False)
             loss.backward(gradient=self._one)
-            taken = not dgr.fuse_pending() and not dgr.stats_pending()
-        if not taken:
-            dgr.fuse_optimizer_into_next_backward(None)
-            dgr.fold_densification_stats_into_next_backward(None, None, None)
+        if not (fold.optimizer_taken and fold.stats_taken):
             raise RuntimeError("graph capture: the rasterizer's backward did not take the optimizer / statistics hand-off")
         status, cap, key = dgr.graph_status_slot(dev)
         self._graph, self._graph_sig = graph, sig
@@ -471,14 +499,7 @@ class Trainer:
         pool.note(g["key"], R)
         self._graph, self._graph_sig = None, None
         self.graph_stats["overflow_reruns"] += 1
-        old = dgr.forward_mode()
-        dgr.set_forward_mode("exact")
-        try:
-            replay, self.graph_replay = self.graph_replay, False
-            self.step(v)
-        finally:
-            self.graph_replay = replay
-            dgr.set_forward_mode(old)
+        self._eager_step([v], forward_mode="exact")
         return False
 
     def finish(self):
@@ -498,7 +519,8 @@ class Trainer:
         changed = False
         if it > d["from_iter"] and it % d["interval"] == 0 and not self._at_capacity():
             # per-view statistics -> identical on all ranks, so every rank takes the same decisions
-            reduce_densification_stats(self.model.xyz_gradient_accum, self.model.denom, self.model.max_radii2D, self.world)
+            reduce_densification_stats(self.model.xyz_gradient_accum, self.model.denom, self.model.max_radii2D, self.world,
+                                       force=self._force_collectives)
             size_threshold = 20 if it > d["reset"] else None
             self.last["densify"] = self.model.densify_and_prune(d["thr"], d["min_opacity"], d["extent"], size_threshold,
                                                                  radii, seed=d["seed"] + it)
@@ -507,4 +529,6 @@ class Trainer:
             self.model.reset_opacity()
             changed = True
         if changed and self.bucket is not None:     # the replaced Parameters are new objects (and carry no gradient yet)
-            self.bucket = GradBucket(self.model.parameters())
+            self.bucket = GradBucket(self._arena_order_params())
+        if changed and self.graph_replay:
+            self._drop_graph()                      # (explicitly: not left to the signature alone)

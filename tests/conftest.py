@@ -14,13 +14,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     # The CPU oracles are torch code: let torch use the CPUs this process really has (a GPU box gives a 16-CPU share of a much
     # bigger host; `os.cpu_count()` threads on that share spin against each other - an oracle-heavy test then takes minutes
-    # instead of seconds, which is what a test that "hung" once in round 3 most likely was)
+    # instead of seconds).  (Whether that, or an unbounded host wait removed in the same round, was behind the one run killed at
+    # its limit in round 3 cannot be told from what that run left behind: profiles/README.md "r3j".)
     import torch
     try:
         n = len(os.sched_getaffinity(0))
     except Exception:       # noqa: BLE001
         n = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(n, int(os.environ.get("GSR_TEST_THREADS", "16")))))
+
+
+def pytest_runtest_logstart(nodeid, location):
+    """One flushed line per test BEFORE it runs (to gpurun_out/, which a GPU box sends back even when the call is killed): a
+    run that ends at its time limit names the test it was in (the round-3 kill `gpurun_out/r3j` left 26 dots and `rc=124`, and
+    its cause could not be established afterwards - profiles/README.md)."""
+    import time
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "pytest_progress.log"), "a") as f:
+            f.write(f"{time.strftime('%H:%M:%S')} pid {os.getpid()} START {nodeid}\n")
+    except OSError:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

@@ -71,7 +71,7 @@ def run_oracle(raw, cam, deg, bg, dtype=torch.float64, mode="sh", antialiasing=F
 
 
 def run_hip(raw, cam, deg, bg, mode="sh", antialiasing=False, scale_modifier=1.0, gc=None, gd=None,
-            cov_precomp=False, debug=False, device="cuda"):
+            cov_precomp=False, debug=False, device="cuda", **call_kw):
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     inp = leaf_inputs(raw, torch.float32, device, mode)
     s = settings_for(cam, deg, bg, scale_modifier, antialiasing, cls=GaussianRasterizationSettings, device=device,
@@ -85,10 +85,12 @@ def run_hip(raw, cam, deg, bg, mode="sh", antialiasing=False, scale_modifier=1.0
     else:
         kw.update(scales=inp["scales"], rotations=inp["rotations"])
     rast = GaussianRasterizer(s)
-    color, radii, invd = rast(means3D=inp["means3D"], means2D=inp["means2D"], opacities=inp["opacities"], **kw)
+    color, radii, invd = rast(means3D=inp["means3D"], means2D=inp["means2D"], opacities=inp["opacities"], **kw, **call_kw)
     grads = None
     if gc is not None:
-        loss = (color * gc.to(device)).sum() + (invd * gd.to(device)).sum()
+        loss = (color * gc.to(device)).sum()
+        if gd is not None:          # (gd=None: no gradient arrives on the inverse-depth image - the kernels' DEPTH = false forms)
+            loss = loss + (invd * gd.to(device)).sum()
         loss.backward()
         grads = {k: (v.grad.detach().cpu() if v.grad is not None else torch.zeros_like(v).cpu()) for k, v in inp.items()}
     torch.cuda.synchronize()

@@ -163,12 +163,11 @@ def test_densification_stats_folded_into_backward_match_the_separate_kernel():
         m = GaussianModel.from_raw(make_gaussians(4000, 2, seed=78, scale_factor=0.7).to("cuda"))
         m.training_setup(optimizer="hip")
         for i, cam in enumerate(cams):
-            pkg = render(cam, m, PipelineParams(), bg, separate_sh=True)
-            if folded:
-                dgr.fold_densification_stats_into_next_backward(m.xyz_gradient_accum, m.denom, m.max_radii2D)
+            fold = dgr.BackwardFold(stats=(m.xyz_gradient_accum, m.denom, m.max_radii2D)) if folded else None
+            pkg = render(cam, m, PipelineParams(), bg, separate_sh=True, fold=fold)
             (pkg["render"] * (1.0 + i)).sum().backward()
             if folded:
-                assert not dgr.stats_pending()
+                assert fold.stats_taken and not fold.optimizer_taken
             else:
                 m.add_densification_stats(pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
             for p in m.parameters():

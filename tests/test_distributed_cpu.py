@@ -299,54 +299,67 @@ def _worker_odd(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_adjacent_spans_grouping_is_address_independent():
-    """Gradients returned side by side in one allocation travel as one collective; the grouping (and the order in which spans
-    come out = the order collectives are issued in) depends on list order and offsets only, never on addresses."""
+def test_span_plan_is_a_function_of_sizes_only():
+    """The collective GradBucket issues per call covers ONE flat span whose length and member offsets follow from the tensors'
+    sizes and order alone (canonical_offsets), so every rank issues the same collective whatever its local memory layout.  The
+    rasterizer's gradient arena has exactly that layout (zero-copy view); anything else is copied into a scratch span."""
     sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-slam_amd"))
-    from scene_utils.parallel import adjacent_spans
-    from diff_gaussian_rasterization import _grad_arena, GRAD_ARENA_ALIGN
-    P = 1001
-    xyz, op, sc, rot, dc, rest, col, cov = _grad_arena("cpu", (((P, 3), 0), ((P, 1), 0), ((P, 3), 0), ((P, 4), 0), ((P, 1, 3), 3),
-                                                               ((P, 15, 3), 0), (None, 0), (None, 0)))
-    assert col is None and cov is None
-    for t in (xyz, op, sc, rot, dc, rest):
-        assert t.is_contiguous() and t.storage_offset() % GRAD_ARENA_ALIGN == 0
-    assert dc.storage_offset() + dc.numel() + 3 <= rest.storage_offset()        # the spare row behind dc
-    lone = torch.zeros(7)
-    spans = adjacent_spans([lone, xyz, op, sc, rot])
-    assert [len(m) for _, m in spans] == [1, 4] and spans[1][1][0] is xyz and spans[1][0].numel() == rot.storage_offset() + rot.numel()
-    # param order of the model (xyz, f_dc, f_rest, opacity, scaling, rotation): still one span, members by offset
-    flat, members = adjacent_spans([xyz, dc, rest, op, sc, rot])[0]
-    assert [m.data_ptr() for m in members] == [t.data_ptr() for t in (xyz, op, sc, rot, dc, rest)]
-    for i, t in enumerate((xyz, op, sc, rot, dc, rest)):
-        t.fill_(float(i + 1))
-    flat.mul_(2.0)
-    assert all(bool((t == 2.0 * (i + 1)).all()) for i, t in enumerate((xyz, op, sc, rot, dc, rest)))
-    # a hole larger than the tolerated gap splits the span: geometry without opacity ... rotation
-    assert [len(m) for _, m in adjacent_spans([xyz, rot])] == [1, 1]
-    # different storages keep list order
-    a, b = torch.zeros(4), torch.zeros(3)
-    assert [f.numel() for f, _ in adjacent_spans([a, b])] == [4, 3] and [f.numel() for f, _ in adjacent_spans([b, a])] == [3, 4]
+    from scene_utils.parallel import canonical_offsets, flat_span, ARENA_ALIGN, ARENA_SPARE
+    from diff_gaussian_rasterization import _grad_arena, GRAD_ARENA_ALIGN, GRAD_ARENA_SPARE
+    assert (ARENA_ALIGN, ARENA_SPARE) == (GRAD_ARENA_ALIGN, GRAD_ARENA_SPARE)
+    for P in (1001, 64, 21, 85, 1):        # (3 P + 3 crossing a 64-float boundary: P = 21, 85; 3 P a multiple of 64: P = 64)
+        xyz, op, sc, rot, dc, rest, col, cov = _grad_arena("cpu", (((P, 3), 0), ((P, 1), 0), ((P, 3), 0), ((P, 4), 0), ((P, 1, 3), 3),
+                                                                   ((P, 15, 3), 0), (None, 0), (None, 0)))
+        assert col is None and cov is None
+        members = (xyz, op, sc, rot, dc, rest)
+        offs, total = canonical_offsets([t.numel() for t in members])
+        assert [t.storage_offset() for t in members] == offs
+        for t in members:
+            assert t.is_contiguous() and t.storage_offset() % GRAD_ARENA_ALIGN == 0
+        assert dc.storage_offset() + dc.numel() + 3 <= rest.storage_offset()        # the spare row behind dc
+        for i, t in enumerate(members):
+            t.fill_(float(i + 1))
+        flat, views = flat_span(list(members))
+        assert views is None and flat.numel() == total and flat.data_ptr() == xyz.data_ptr()       # the arena itself: no copy
+        flat.mul_(2.0)
+        assert all(bool((t == 2.0 * (i + 1)).all()) for i, t in enumerate(members))
+        # sub-spans the trainer uses: geometry, and dc + rest
+        f2, v2 = flat_span([xyz, op, sc, rot])
+        assert v2 is None and f2.numel() == rot.storage_offset() + rot.numel()
+        f3, v3 = flat_span([dc, rest])
+        assert v3 is None and f3.data_ptr() == dc.data_ptr() and f3.numel() == rest.storage_offset() - dc.storage_offset() + rest.numel()
+        # any other local layout: same length, copies
+        plain = [t.clone() for t in members]
+        f4, v4 = flat_span(plain)
+        assert v4 is not None and f4.numel() == total and all(torch.equal(v, t) for v, t in zip(v4, plain))
+        f5, v5 = flat_span([xyz, dc, rest, op, sc, rot])                  # model order is not the arena's order: copies, same sizes
+        assert v5 is not None and f5.numel() == canonical_offsets([t.numel() for t in (xyz, dc, rest, op, sc, rot)])[1]
+        f6, v6 = flat_span([xyz, rot])                                    # members with a hole between them
+        assert v6 is not None
 
 
 def test_all_reduce_mean_of_arena_gradients_two_ranks(tmp_path):
-    """GradBucket.all_reduce_mean with the gradients in one arena (one collective over the span) gives the per-tensor mean."""
-    port = 35000 + (os.getpid() % 2000)
-    mp.spawn(_worker_arena, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    a, b = (torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(2))
-    for x, y, m in zip(a["got"], b["got"], a["expect"]):
-        assert torch.equal(x, y) and torch.equal(x, m)
-    assert a["spans"] == b["spans"] == 1
+    """GradBucket.all_reduce_mean with the gradients in one arena (one collective over the span, no copy) gives the per-tensor
+    mean - and so does a rank whose gradients are PLAIN tensors while its peer's are an arena (the span plan must not
+    depend on a rank's local layout; the mismatch used to mean different collectives on the two ranks)."""
+    for mixed in (False, True):
+        d = tmp_path / ("mixed" if mixed else "arena")
+        d.mkdir()
+        port = 35000 + (os.getpid() % 2000) + (11 if mixed else 0)
+        mp.spawn(_worker_arena, args=(2, port, str(d), mixed), nprocs=2, join=True)
+        a, b = (torch.load(os.path.join(d, f"r{r}.pt")) for r in range(2))
+        for x, y, m in zip(a["got"], b["got"], a["expect"]):
+            assert torch.equal(x, y) and torch.equal(x, m)
+        assert a["copied"] == 0 and b["copied"] == (1 if mixed else 0)
 
 
-def _worker_arena(rank, world, port, out_dir):
+def _worker_arena(rank, world, port, out_dir, mixed=False):
     for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     from scene_utils import init_from_env, GradBucket
-    from scene_utils.parallel import adjacent_spans
     from diff_gaussian_rasterization import _grad_arena
     init_from_env("gloo")
     P = 333
@@ -356,13 +369,168 @@ def _worker_arena(rank, world, port, out_dir):
     for r in range(world):
         gen = torch.Generator().manual_seed(50 + r)
         per_rank.append([torch.randn(s, generator=gen) for s in shapes])
-    grads = _grad_arena("cpu", tuple((s, 0) for s in shapes))
-    for p, g, src in zip(params, grads, per_rank[rank]):
-        g.copy_(src)
-        p.grad = g
-    n_spans = len(adjacent_spans([p.grad for p in params]))
-    GradBucket(params).all_reduce_mean(world)
+    if mixed and rank == 1:
+        # this rank's gradients are not arena views: one was cloned by autograd, one is missing (None -> zeros), one is not
+        # contiguous.  (The missing one contributes zeros to the mean.)
+        per_rank[1][1] = torch.zeros(shapes[1])
+        params[0].grad = per_rank[1][0].clone()
+        params[1].grad = None
+        params[2].grad = per_rank[1][2].t().contiguous().t()
+        params[3].grad = per_rank[1][3].clone()
+    else:
+        if mixed:
+            per_rank[1][1] = torch.zeros(shapes[1])
+        grads = _grad_arena("cpu", tuple((s, 0) for s in shapes))
+        for p, g, src in zip(params, grads, per_rank[rank]):
+            g.copy_(src)
+            p.grad = g
+    bucket = GradBucket(params)
+    bucket.all_reduce_mean(world)
     expect = [(a + b) * (1.0 / world) for a, b in zip(*per_rank)]
-    torch.save(dict(got=[p.grad.clone() for p in params], expect=expect, spans=n_spans), os.path.join(out_dir, f"r{rank}.pt"))
+    torch.save(dict(got=[p.grad.clone() for p in params], expect=expect, copied=bucket.copied_spans), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_world_one_helpers_do_nothing_even_when_a_process_group_exists(tmp_path):
+    """`all_reduce_mean(world=1)` / `reduce_densification_stats(world=1)` must not touch the default group of an
+    unrelated launcher (independent replicas per rank); only `force=True` (Trainer(single_rank_group=True)) runs them."""
+    port = 36000 + (os.getpid() % 2000)
+    mp.spawn(_worker_world_one, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(2))
+    assert a["grad"] == 1.0 and b["grad"] == 2.0 and a["accum"] == 1.0 and b["accum"] == 2.0      # untouched: no cross-rank sum
+    assert a["forced"] == b["forced"] == 1.5                                                    # force=True did run the mean
+
+
+def _worker_world_one(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from scene_utils import init_from_env, GradBucket, reduce_densification_stats
+    init_from_env("gloo")
+    p = torch.nn.Parameter(torch.zeros(5, 3))
+    p.grad = torch.full((5, 3), float(rank + 1))
+    GradBucket([p]).all_reduce_mean(1)                       # this replica trains on its own
+    acc, den, mr = torch.full((5, 1), float(rank + 1)), torch.ones(5, 1), torch.zeros(5)
+    reduce_densification_stats(acc, den, mr, 1)
+    q = torch.nn.Parameter(torch.zeros(5, 3))
+    q.grad = torch.full((5, 3), float(rank + 1))
+    GradBucket([q]).all_reduce_mean(1, force=True)            # (gloo: SUM / world with world = 1 -> the plain sum of both ranks)
+    torch.save(dict(grad=float(p.grad[0, 0]), accum=float(acc[0, 0]), forced=float(q.grad[0, 0]) / world), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# world_size 8: the rank count north_star fixes.  Every exchange, P not divisible by 8, 100 views sharded r::8.
+# ---------------------------------------------------------------------------------------------------------------------------
+P8, VIEWS8, STEPS8 = 123, 100, 2
+EXCHANGES8 = ("allreduce", "sharded", "visible_rows", "sh_rank1")
+
+
+def _scene8():
+    from scene_utils import make_gaussians, fibonacci_cameras
+    raw = make_gaussians(P8, 1, seed=15, scale_factor=1.2)
+    cams = fibonacci_cameras(VIEWS8, 24, 24, seed=16)
+    gts = {i: torch.rand(3, 24, 24, generator=torch.Generator().manual_seed(300 + i)).double() for i in range(VIEWS8)}
+    return raw, cams, gts
+
+
+def _model8(raw):
+    """float64 parameters: what this test compares is the LOGIC of the exchanges (sharding, left-over rows, union masks, the 8-way
+    rank-one rebuild) against a single process, so the tolerance can be tight (1e-9) and independent of the order in which a
+    collective adds its 8 terms (gloo's ring reduces a 7 k-element span in another order than six small tensors).  The float32
+    path is compared bit for bit at N = 2 above, where a two-term sum is order-free."""
+    from scene_utils import GaussianModel
+    m = GaussianModel.from_raw(raw)
+    for p in m.parameters():
+        p.data = p.data.double()
+    return m
+
+
+def _worker8(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-slam_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from scene_utils import init_from_env, shard_views, Trainer, GaussianModel, reduce_densification_stats
+    from oracle.loss_oracle import training_loss
+    from gaussian_renderer import PipelineParams
+    r, w, _ = init_from_env("gloo")
+    raw, cams, gts = _scene8()
+    mine = shard_views(VIEWS8, r, w)
+    res = {"views": mine}
+    for ex in EXCHANGES8:
+        model = _model8(raw)
+        tr = Trainer(model, cams, gts, _oracle_render, PipelineParams(), torch.zeros(3), world=w, rank=r, optimizer="torch",
+                     loss=training_loss, exchange=ex)
+        for v in mine[:STEPS8]:
+            tr.step(v)
+        reduce_densification_stats(tr.xyz_gradient_accum, tr.denom, tr.max_radii2D, w)
+        res[ex] = {"params": [p.detach().clone() for p in model.parameters()], "accum": tr.xyz_gradient_accum.clone(),
+                   "denom": tr.denom.clone(), "maxr": tr.max_radii2D.clone(),
+                   "moment_bytes": tr.sharded.moment_bytes() if tr.sharded is not None else None}
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+def test_eight_ranks_every_exchange_equals_the_mean_gradient_step(tmp_path):
+    """north_star's rank count.  8 gloo ranks, 123 Gaussians (123 mod 8 = 3 left-over rows in ShardedStep), 100 views sharded
+    r::8, two optimizer steps (views r and r + 8), all four exchanges.  Within an exchange all 8 ranks end bit-identical (the
+    8-way in-order sum of the rank-one SH rebuild included); against a single-process Adam on the mean of the 8 per-view
+    gradients every exchange's parameters agree to |d| <= 1e-9 + 1e-7 |p| (float64 parameters, see _model8)."""
+    world = 8
+    port = 37000 + (os.getpid() % 2000)
+    mp.spawn(_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    # r::8 sharding of 100 views: a partition, sizes 13 / 12
+    assert sorted(v for o in outs for v in o["views"]) == list(range(VIEWS8))
+    assert [len(o["views"]) for o in outs] == [13, 13, 13, 13, 12, 12, 12, 12]
+    assert all(o["views"][:2] == [r, r + 8] for r, o in enumerate(outs))
+    for ex in EXCHANGES8:
+        for o in outs[1:]:
+            for pa, pb in zip(outs[0][ex]["params"], o[ex]["params"]):
+                assert torch.equal(pa, pb), ex
+            for k in ("accum", "denom", "maxr"):
+                assert torch.equal(outs[0][ex][k], o[ex][k]), (ex, k)
+    full = sum(p.numel() for p in outs[0]["allreduce"]["params"]) * 4 * 2
+    rows = P8 // world + P8 % world                  # 15-row shard + the 3 left-over rows every rank keeps
+    assert outs[0]["sharded"]["moment_bytes"] == full // P8 * rows
+
+    # single-process reference: Adam on the mean of the 8 per-view gradients, twice
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-slam_amd"))
+    from scene_utils import GaussianModel
+    from oracle.loss_oracle import training_loss
+    from gaussian_renderer import PipelineParams
+    raw, cams, gts = _scene8()
+    model = _model8(raw)
+    opt = torch.optim.Adam(model.param_groups(), lr=0.0, eps=1e-15)
+    accum = torch.zeros(P8, 1); denom = torch.zeros(P8, 1); maxr = torch.zeros(P8)
+    for step in range(STEPS8):
+        grads = [torch.zeros_like(p) for p in model.parameters()]
+        for r in range(world):
+            v = r + world * step
+            pkg = _oracle_render(cams[v], model, PipelineParams(), torch.zeros(3))
+            training_loss(pkg["render"], gts[v]).backward()
+            vis = pkg["visibility_filter"]
+            accum[vis] += torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)
+            denom[vis] += 1
+            maxr[vis] = torch.max(maxr[vis], pkg["radii"][vis].float())
+            for g, p in zip(grads, model.parameters()):
+                g += p.grad
+                p.grad = None
+        for g, p in zip(grads, model.parameters()):
+            p.grad = g / world
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    moved = False
+    for ex in EXCHANGES8:
+        for pa, p, p0 in zip(outs[0][ex]["params"], model.parameters(), GaussianModel.from_raw(raw).parameters()):
+            assert pa.dtype == torch.float64
+            assert torch.allclose(pa, p.detach(), atol=1e-9, rtol=1e-7), (ex, float((pa - p.detach()).abs().max()))
+            moved |= bool((pa != p0.detach().double()).any())
+        assert torch.allclose(outs[0][ex]["accum"], accum, atol=1e-5) and torch.equal(outs[0][ex]["denom"], denom)
+        assert torch.equal(outs[0][ex]["maxr"], maxr)
+    assert moved

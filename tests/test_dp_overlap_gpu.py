@@ -52,6 +52,31 @@ def test_bench_gpus_2_starts_two_ranks_itself(exchange):
     assert r2.returncode != 0 and "refusing" in r2.stderr
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("exchange", ["sh_rank1", "allreduce", "sharded"])
+def test_bench_launches_three_ranks_on_the_shared_card(exchange):
+    """More than two ranks on the test box.  Its process guard admits SIX processes with the card open, and this pytest process
+    and bench.py's launching parent are two of them (a 5-rank attempt was killed by the guard: 7 processes, gpurun_out/r4b) - so
+    3 ranks here; north_star's 8 ranks run under gloo on the CPU (tests/test_distributed_cpu.py::
+    test_eight_ranks_every_exchange_equals_the_mean_gradient_step).  `python bench.py --gpus 3` with no launcher: starts the ranks
+    itself, 10 000 Gaussians (10 000 mod 3 = 1: ShardedStep's left-over row) and 7 views (7 mod 3 = 1: ranks get 3 / 2 / 2),
+    overlapped exchange where the schedule has one (the default at N > 1), gloo between the ranks.  Asserts rc 0, n_gpus 3 and the
+    exchange figure of the JSON line."""
+    import json
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "3", "--warmup", "1", "--config", "1",
+           "--views", "7", "--no-cpu-baseline", "--no-kernel-profile", "--optimizer", "hip", "--exchange", exchange]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["steps"] == 3 and d["value"] > 0 and d["config"]["exchange"] == exchange
+    row = 4 * (11 + 3 * 1)                                                                       # SH degree 0 at C1: 14 floats
+    from_table = {"sh_rank1": 2 * 2 / 3 * 44 + 2 * 12, "allreduce": 2 * 2 / 3 * row, "sharded": 2 * 2 / 3 * row}[exchange]
+    assert abs(d["config"]["exchange_bytes_per_gaussian_received"] - from_table) < 0.1
+
+
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
 def test_sh_rank1_expand_kernel_against_torch(deg):
     """csrc/exchange.hip against the same arithmetic in torch ops (scene_utils.parallel's CPU branch): three "ranks", a third of

@@ -108,3 +108,49 @@ def test_graph_replay_across_densifications(min_opacity):
         assert stats["captures"] >= 3 and stats["replays"] >= 8 and ref[0].shape[0] > 3000
     else:
         assert ref[0].shape[0] == 0 and stats["captures"] == 1
+
+
+def test_opacity_reset_between_two_replays_drops_the_graph():
+    """`reset_opacity` replaces `_opacity` and its two Adam moments and leaves `_xyz` / `_features_rest` alone.  With
+    the model at `max_gaussians` the reset iterations (5, 10, 15) change nothing else, so a signature of sizes + those two
+    addresses kept replaying a graph whose baked pointers were the OLD opacity tensor and moments (freed memory; the real
+    `_opacity` never trained again).  The graph is now dropped whenever densification / reset changed anything, and the signature
+    covers every parameter, moment and statistics address: same end state as the eager loop, bit for bit, moments included."""
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import make_gaussians, fibonacci_cameras, GaussianModel, Trainer
+    dev = "cuda"
+    cams = fibonacci_cameras(3, 160, 96, seed=61, device=dev)
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams()
+    teacher = GaussianModel.from_raw(make_gaussians(3000, 1, seed=62, scale_factor=0.8).to(dev), requires_grad=False)
+    with torch.no_grad():
+        gts = {i: render(c, teacher, pipe, bg)["render"].clone() for i, c in enumerate(cams)}
+    ends = []
+    for graph in (False, True):
+        model = GaussianModel.from_raw(make_gaussians(3000, 1, seed=63, scale_factor=0.8).to(dev))
+        tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True, optimizer="hip_fused", lambda_dssim=0.2)
+        tr.enable_densification(extent=4.4, from_iter=3, until_iter=100, interval=6, opacity_reset_interval=5,
+                                grad_threshold=2e-5, min_opacity=0.005, seed=7, max_gaussians=3000)
+        if graph:
+            tr.enable_graph_replay(warmup=1)
+        opacity_ptrs = set()
+        for it in range(19):
+            tr.step(it % 3)
+            opacity_ptrs.add(model._opacity.data_ptr())
+        tr.finish()
+        torch.cuda.synchronize()
+        out = []
+        for p in model.parameters():
+            st = tr.optimizer.state[p]
+            out += [p.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()]
+        ends.append((out, tr.graph_stats if graph else None, len(opacity_ptrs), int(model.get_xyz.shape[0])))
+    (ref, _, n_ref, P_ref), (got, stats, n_got, P_got) = ends
+    assert P_ref == P_got == 3000 and n_ref >= 2 and n_got >= 2          # the resets did replace the opacity tensor
+    assert stats["captures"] >= 4 and stats["replays"] >= 8               # one capture per stretch between resets
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+    # the scalars baked into a captured step are part of the signature too
+    tr.lambda_dssim = 0.3
+    sig_a = tr._graph_signature(cams[0])
+    tr.lambda_dssim = 0.2
+    assert sig_a != tr._graph_signature(cams[0])

@@ -123,6 +123,75 @@ def test_fused_l1_ssim_loss_matches_reference_loss(shape, lam):
     assert v2.item() == val.item() and torch.equal(a2.grad, a_gpu.grad)
 
 
+def test_fold_request_travels_with_its_call_unrelated_renders_in_between_take_nothing():
+    """SURVEY 8(b) "no global state, re-entrant": the optimizer / statistics fold is an argument of ONE rasterizer call and lives on
+    that call's autograd ctx.  Between arming it (the render) and its backward, a viewer-style render of ANOTHER model with its own
+    grad-enabled backward - and a forward-only render of the same model - run untouched: they neither consume the fold nor get
+    stepped by it, and the folded step still happens on the right call, bit-identical to backward + optimizer.step()."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render, PipelineParams
+    from scene_utils import make_gaussians, fibonacci_cameras, GaussianModel
+    from scene_utils.losses import training_loss_fused
+    cams = fibonacci_cameras(3, 160, 96, seed=191, device="cuda")
+    bg = torch.tensor([0.1, 0.2, 0.05], device="cuda")
+    pipe = PipelineParams()
+    gen = torch.Generator().manual_seed(192)
+    gt = torch.rand(3, 96, 160, generator=gen).cuda()
+    up = torch.randn(3, 96, 160, generator=gen).cuda()
+
+    def viewer_grads():
+        other = GaussianModel.from_raw(make_gaussians(1500, 2, seed=194, scale_factor=0.8).to("cuda"))
+        pkg = render(cams[1], other, pipe, bg, separate_sh=True)
+        (pkg["render"] * up).sum().backward()
+        return other, [p.grad.clone() for p in other.parameters()]
+
+    _, plain_viewer = viewer_grads()
+    res = {}
+    for folded in (False, True):
+        model = GaussianModel.from_raw(make_gaussians(2500, 3, seed=193, scale_factor=0.7).to("cuda"))
+        opt = model.training_setup(optimizer="hip")
+        for it in range(3):
+            fold = dgr.BackwardFold(optimizer=opt, stats=(model.xyz_gradient_accum, model.denom, model.max_radii2D)) if folded else None
+            pkg = render(cams[it % 3], model, pipe, bg, separate_sh=True, fold=fold)
+            loss = training_loss_fused(pkg["render"], gt, 0.2)
+            # --- somebody else renders in between ---
+            other, got = viewer_grads()
+            for a, b in zip(got, plain_viewer):
+                assert torch.equal(a, b)                                   # the viewer's backward is an ordinary one
+            with torch.no_grad():
+                render(cams[2], model, pipe, bg, separate_sh=True)         # forward-only render of the SAME model
+            if folded:
+                assert not fold.optimizer_taken and not fold.stats_taken   # nobody consumed the request
+            # --- now the armed call's backward ---
+            loss.backward()
+            if folded:
+                assert fold.optimizer_taken and fold.stats_taken
+                assert all(p.grad is None for p in model.parameters())     # the step rode in the backward: nothing materialised
+            else:
+                model.add_densification_stats(pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        res[folded] = [(p.detach().clone(), opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
+                       for p in model.parameters()] + [(model.xyz_gradient_accum.clone(), model.denom.clone(), model.max_radii2D.clone())]
+    for a, b in zip(res[False], res[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    # a retained graph's second backward does not step a second time
+    model = GaussianModel.from_raw(make_gaussians(800, 1, seed=195, scale_factor=0.9).to("cuda"))
+    opt = model.training_setup(optimizer="hip")
+    fold = dgr.BackwardFold(optimizer=opt)
+    pkg = render(cams[0], model, pipe, bg, separate_sh=True, fold=fold)
+    l = (pkg["render"] * up).sum()
+    l.backward(retain_graph=True)
+    after_first = [p.detach().clone() for p in model.parameters()]
+    assert fold.optimizer_taken and all(p.grad is None for p in model.parameters())
+    l.backward()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(after_first, model.parameters()))
+    assert all(p.grad is not None for p in model.parameters() if p.numel())    # the second one is a plain backward
+
+
 @pytest.mark.parametrize("kind", ["hip", "hip_sparse"])
 def test_optimizer_step_folded_into_backward_is_bit_identical(kind):
     """gsr_backward_adam (the Adam / SparseGaussianAdam update applied by the rasterizer backward's last kernel, gradients
@@ -141,12 +210,12 @@ def test_optimizer_step_folded_into_backward_is_bit_identical(kind):
     for fused in (False, True):
         model = GaussianModel.from_raw(make_gaussians(3000, 3, seed=93, scale_factor=0.7).to("cuda"))
         tr = Trainer(model, cams, gts, render, pipe, bg, separate_sh=True, optimizer=kind + ("_fused" if fused else ""))
-        n0 = dgr.fused_backward_count
+        n0 = dgr.call_stats().get("folded_backwards", 0)
         for it in range(7):
             tr.step(it % 3)
         tr.finish()
         torch.cuda.synchronize()
-        assert dgr.fused_backward_count - n0 == (7 if fused else 0)
+        assert dgr.call_stats().get("folded_backwards", 0) - n0 == (7 if fused else 0)
         st = {}
         for name, p in zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), model.parameters()):
             s = tr.optimizer.state[p]

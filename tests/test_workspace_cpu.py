@@ -119,25 +119,59 @@ def test_verified_frames_need_no_event_the_status_sentinel_tells():
 
 
 def test_dc_gradient_tail_row_is_recognised_only_for_the_backwards_own_tensor():
-    """The backward returns its dc gradient with three spare floats behind it; `dc_grad_tail_row` hands out the [P + 1, 3] view over
-    both only for THAT tensor (same storage position and size) - a copy, another tensor or a stale record gets None and the caller
-    concatenates."""
+    """The backward returns its gradients in one arena with three spare floats behind each; `dc_grad_tail_row` hands out the
+    [P + 1, 3] view over a dc gradient and its spare row only while the tensor still IS that allocation's - the knowledge rides on
+    the arena's storage object (no process-wide "most recent backward"): it survives autograd moving the tensor into `.grad`, and a
+    copy, a sum accumulated elsewhere, another backward's arena or a tensor that is no arena member gets None (the caller then
+    concatenates)."""
     import diff_gaussian_rasterization as dgr
     P = 37
-    xyz, op, sc, rot, dc, rest, _, _ = dgr._grad_arena("cpu", (((P, 3), 0), ((P, 1), 0), ((P, 3), 0), ((P, 4), 0), ((P, 1, 3), 3),
-                                                               ((P, 15, 3), 0), (None, 0), (None, 0)))
-    old = dgr._last_dc_grad
-    try:
-        dgr._last_dc_grad = (dc.data_ptr(), dc.numel())
-        dc.copy_(torch.arange(3 * P, dtype=torch.float32).view(P, 1, 3))
-        rest.fill_(-5.0)
-        tail = dgr.dc_grad_tail_row(dc)
-        assert tail is not None and tail.shape == (P + 1, 3) and tail.data_ptr() == dc.data_ptr()
-        assert torch.equal(tail[:P], dc.view(P, 3))
-        tail[P] = torch.tensor([7.0, 8.0, 9.0])
-        assert bool((rest == -5.0).all())                      # the spare row lies in front of the next tensor
-        assert dgr.dc_grad_tail_row(dc.clone()) is None and dgr.dc_grad_tail_row(xyz.view(P, 1, 3)) is None
-        dgr._last_dc_grad = None
-        assert dgr.dc_grad_tail_row(dc) is None
-    finally:
-        dgr._last_dc_grad = old
+    parts = (((P, 3), 0), ((P, 1), 0), ((P, 3), 0), ((P, 4), 0), ((P, 1, 3), 3), ((P, 15, 3), 0), (None, 0), (None, 0))
+    xyz, op, sc, rot, dc, rest, _, _ = dgr._grad_arena("cpu", parts)
+    dc.copy_(torch.arange(3 * P, dtype=torch.float32).view(P, 1, 3))
+    rest.fill_(-5.0)
+    tail = dgr.dc_grad_tail_row(dc)
+    assert tail is not None and tail.shape == (P + 1, 3) and tail.data_ptr() == dc.data_ptr()
+    assert torch.equal(tail[:P], dc.view(P, 3))
+    tail[P] = torch.tensor([7.0, 8.0, 9.0])
+    assert bool((rest == -5.0).all())                      # the spare row lies in front of the next tensor
+    assert dgr.dc_grad_tail_row(dc.clone()) is None
+    assert dgr.dc_grad_tail_row(torch.zeros(P, 1, 3)) is None
+    assert dgr.dc_grad_tail_row(dc.view(-1)[3:].view(P - 1, 1, 3)) is None          # same storage, not a member of the arena
+    # two arenas alive at once (two devices' / two threads' / two interleaved backwards): each answers for its own tensor
+    other = dgr._grad_arena("cpu", parts)[4]
+    assert dgr.dc_grad_tail_row(other).data_ptr() == other.data_ptr() and dgr.dc_grad_tail_row(dc).data_ptr() == dc.data_ptr()
+
+    # through autograd: a gradient the engine moves into `.grad` keeps its arena; an accumulated one does not
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            out = dgr._grad_arena("cpu", (((P, 1, 3), 3),))[0]
+            out.fill_(1.0)
+            return out
+    a = torch.nn.Parameter(torch.zeros(P, 1, 3))
+    Fn.apply(a).sum().backward()
+    assert dgr.dc_grad_tail_row(a.grad) is not None and dgr.dc_grad_tail_row(a.grad).shape == (P + 1, 3)
+    b = torch.nn.Parameter(torch.zeros(P, 1, 3))
+    (Fn.apply(b) + Fn.apply(b)).sum().backward()
+    assert dgr.dc_grad_tail_row(b.grad) is None
+
+
+def test_no_process_wide_hand_offs_are_left_in_the_rasterizer_module():
+    """no global state, re-entrant per device.  The optimizer fold, the statistics fold, the skipped dL/dsh_rest, the
+    SH-ready event and the forward mode of a call travel as arguments of that call (BackwardFold on its autograd ctx)."""
+    import inspect
+    import diff_gaussian_rasterization as dgr
+    for name in ("_fused_optimizer", "_fold_stats", "_skip_sh_rest", "_sh_ready_event", "_last_dc_grad", "_split_rows",
+                 "fuse_optimizer_into_next_backward", "fold_densification_stats_into_next_backward",
+                 "skip_sh_rest_grad_in_next_backward", "defer_sh_until"):
+        assert not hasattr(dgr, name), name
+    sig = inspect.signature(dgr.GaussianRasterizer.forward)
+    for kw in ("fold", "sh_ready_event", "forward_mode"):
+        assert sig.parameters[kw].kind is inspect.Parameter.KEYWORD_ONLY and sig.parameters[kw].default is None
+    f = dgr.BackwardFold(optimizer=None, stats=(None, None, None))
+    assert f.stats is None and not (f.optimizer_taken or f.stats_taken or f.sh_rest_skipped)

@@ -44,10 +44,9 @@ def main():
                 lib.gsr_profile_reset()
                 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
                 t0.record()
-            pkg = render(cams[it % 8], model, pipe, bg, separate_sh=True)
+            fold = dgr.BackwardFold(skip_sh_rest=True) if variant == "rank1_fused" else None
+            pkg = render(cams[it % 8], model, pipe, bg, separate_sh=True, fold=fold)
             loss = training_loss_fused(pkg["render"], gt, 0.2)
-            if variant == "rank1_fused":
-                dgr.skip_sh_rest_grad_in_next_backward()
             loss.backward()
             with torch.no_grad():
                 if variant != "allreduce":
