@@ -56,13 +56,13 @@ def build_scene(args, device, rank, world):
     from scene_utils import make_config, GaussianModel, make_gaussians
     from gaussian_renderer import render, PipelineParams
     raw, cams, cfg = make_config(args.config, device="cpu", P=args.gaussians, views=args.views,
-                                 W=args.width, H=args.height)
+                                 W=args.width, H=args.height, splat_scale=args.scale_factor)
     for c in cams:
         c.to(device)
     pipe = PipelineParams(antialiasing=bool(cfg.get("antialiasing", False)))
     bg = torch.zeros(3, device=device)
     # hidden "teacher": same recipe, different seed for colour/opacity perturbation -> ground-truth images
-    teacher_raw = make_gaussians(cfg["P"], cfg["deg"], 1000 * args.config)
+    teacher_raw = make_gaussians(cfg["P"], cfg["deg"], 1000 * args.config, scale_factor=0.25 * args.scale_factor)
     gen = torch.Generator().manual_seed(1000 * args.config + 7)
     teacher_raw.features_dc += 0.3 * torch.randn(teacher_raw.features_dc.shape, generator=gen)
     teacher_raw.xyz += 0.002 * torch.randn(teacher_raw.xyz.shape, generator=gen)
@@ -260,6 +260,10 @@ def main():
     ap.add_argument("--views", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--scale-factor", type=float, default=1.0,
+                    help="multiplier on the recipe's splat size (SURVEY App. C).  1.0 = the BASELINE configs; 2.0 = the same scene "
+                         "with twice the splat size: ~3.5x the tile instances per Gaussian, the compositing kernels dominate as on "
+                         "a real capture (profiles/r04_bench_c3_heavy.json).  The JSON line names it in config.workload")
     ap.add_argument("--cpu-tiles", type=int, default=256)
     ap.add_argument("--optimizer", default="hip_fused", choices=["hip", "hip_fused", "hip_sparse", "hip_sparse_fused", "torch"],
                     help="hip: one-launch Adam kernel (torch.optim.Adam semantics, the reference's default optimizer); "
@@ -462,7 +466,9 @@ def main():
                          "tile_local_frames_timed": timed_stats.get("tile_local_frames", 0)
                                                     - stats_before.get("tile_local_frames", 0)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{args.config - 1}]: {P} Gaussians, SH degree {cfg['deg']}, "
+        "config": {"workload": (f"NOT a BASELINE config - configs[{args.config - 1}] with {args.scale_factor}x the recipe's splat size: "
+                                if args.scale_factor != 1.0 else f"BASELINE configs[{args.config - 1}]: ") +
+                               f"{P} Gaussians, SH degree {cfg['deg']}, "
                                f"{W}x{H}, {len(cams)} views, one view per rank per step, mean of the ranks' "
                                f"{59 if cfg['deg'] == 3 else 11 + 3 * M}-float/Gaussian gradients over RCCL when N>1 "
                                f"(exchange: {trainer.exchange})",
@@ -537,7 +543,7 @@ def main():
         if "fwd_pairs" in pe:
             flops["render_fwd"] = FWD_FLOP_PER_PAIR * pe["fwd_pairs"] + FWD_FLOP_PER_BLEND * pe.get("fwd_blended", 0)
             flops["render_bwd"] = BWD_FLOP_PER_PAIR * pe["bwd_pairs"]
-        cfg_key = f"c{args.config}:{P}:{W}x{H}"
+        cfg_key = f"c{args.config}:{P}:{W}x{H}" + (f":s{args.scale_factor}" if args.scale_factor != 1.0 else "")
 
         def roof_of(name):
             d = kt[name]

@@ -72,7 +72,9 @@ int gsr_launch_status(const char* what) {
   return gsr_check(hipGetLastError(), what);
 }
 
-static int debug_sync(const gsr_settings* s, hipStream_t st, const char* stage) {
+// status0: the frame's first status word on the device (meta[0]); with debug = 1 a stage that left GSR_STATUS_SORT_TIMEOUT there
+// fails the call (reference README.md:168-171: with --debug a failing rasterizer call raises and dumps its inputs).
+static int debug_sync(const gsr_settings* s, hipStream_t st, const char* stage, const uint32_t* status0 = nullptr) {
   static const bool trace = getenv("GSR_TRACE") != nullptr;   // GSR_TRACE=1: name every stage on stderr as it completes
   if (trace) {
     fprintf(stderr, "[gsr] launched: %s\n", stage);
@@ -87,6 +89,14 @@ static int debug_sync(const gsr_settings* s, hipStream_t st, const char* stage) 
   if (e != hipSuccess) {
     gsr_set_error("debug: failure after stage '%s': %s", stage, hipGetErrorString(e));
     return GSR_ERR_HIP;
+  }
+  if (status0) {
+    uint32_t w = 0;
+    if (hipMemcpy(&w, status0, 4, hipMemcpyDeviceToHost) == hipSuccess && (w & GSR_STATUS_SORT_TIMEOUT)) {
+      gsr_set_error("debug: stage '%s': a radix-sort look-back wait timed out (inter-workgroup hand-off broken): the frame is "
+                    "mis-sorted", stage);
+      return GSR_ERR_HIP;
+    }
   }
   return 0;
 }
@@ -341,9 +351,9 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   const int where = gsr_radix_sort_pairs((uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order),
                                          (uint32_t*)(geom + L.key_tmp), (uint32_t*)(geom + L.val_tmp),
                                          /*vals_iota=*/true, (size_t)P, 32, (uint32_t*)(geom + L.radix_tmp), st, nullptr,
-                                         nullptr, nullptr, /*head_zeroed=*/true);
+                                         nullptr, nullptr, /*head_zeroed=*/true, /*fail_flags=*/meta);
   if (where != 0) { gsr_set_error("internal: depth sort ended in the wrong buffer"); return GSR_ERR_HIP; }
-  if ((rc = debug_sync(s, st, "depth sort"))) return rc;
+  if ((rc = debug_sync(s, st, "depth sort", meta))) return rc;
 
   // inclusive prefix sum of tiles_touched in depth order (its last element equals num_rendered)
   gsr_scan_u32((const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.order),
@@ -503,12 +513,14 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
             ? gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.val_a), (uint32_t*)(bin + BL.key_b),
                                    (uint32_t*)(bin + BL.val_b), /*vals_iota=*/true, R, tile_bits(tiles),
                                    (uint32_t*)(bin + BL.radix_tmp), st, (uint32_t*)(bin + BL.gauss_of_slot),
-                                   (uint32_t*)(bin + BL.point_list), n_dev, /*head_zeroed (by the emit kernel)=*/true)
+                                   (uint32_t*)(bin + BL.point_list), n_dev, /*head_zeroed (by the emit kernel)=*/true,
+                                   /*fail_flags=*/(uint32_t*)(geom + GL.meta))
             : gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
                                    (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.point_list), /*vals_iota=*/false, R,
-                                   tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st, nullptr, nullptr, n_dev, true);
+                                   tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st, nullptr, nullptr, n_dev, true,
+                                   (uint32_t*)(geom + GL.meta));
     if (where != tile_sort_result_buffer(tiles)) { gsr_set_error("internal: tile sort buffer parity"); return GSR_ERR_HIP; }
-    if ((rc = debug_sync(s, st, "tile sort"))) return rc;
+    if ((rc = debug_sync(s, st, "tile sort", (const uint32_t*)(geom + GL.meta)))) return rc;
     const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
     gsr_launch_finalize((uint32_t)R, n_dev, ks, bin, BL, st);
     if ((rc = debug_sync(s, st, "finalize bins"))) return rc;

@@ -220,7 +220,11 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 // caller that does not know the count on the host: gsr_forward_async).
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
                          int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0 = nullptr, uint32_t* w1 = nullptr,
-                         const uint32_t* n_dev = nullptr, bool head_zeroed = false);
+                         const uint32_t* n_dev = nullptr, bool head_zeroed = false, uint32_t* fail_flags = nullptr);
+// fail_flags: the frame's first status word (geometry state meta[0], handed to the host as status word 0): a look-back wait that
+// times out (a broken hand-off protocol: the pass then goes on with a WRONG base, the grid drains, the frame is mis-sorted) ORs
+// GSR_STATUS_SORT_TIMEOUT into it, so the failure reaches the caller instead of staying a mark in device memory.
+#define GSR_STATUS_SORT_TIMEOUT 1u
 // head_zeroed: the caller guarantees that the first GSR_RADIX_HEAD_WORDS words of `tmp` are zero when the sort's first kernel
 // starts (an earlier kernel of the same stream cleared them); otherwise the sort enqueues a memset of its own.
 

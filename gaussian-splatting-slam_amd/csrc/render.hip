@@ -17,6 +17,7 @@
 // Record = (sum h dx, sum h dy, sum h dx^2, sum h dx dy) (sum h dy^2, sum h = dL/dopacity_eff, d_r, d_g) (d_b, d_invdepth, -, -)
 // with h = dL/dpower / opacity_eff (the per-pixel dL/dopacity_eff) and d = mean - pixel: raw moments; k_preprocess_bwd turns
 // their per-Gaussian totals, times opacity_eff, into dL/dmean2D and dL/dconic.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -489,7 +490,7 @@ __device__ __forceinline__ uint32_t gsr_subblock_mask(const float4& r0, const fl
 // MASK = true (round 4, the default): sub-block masks from the staging step (gsr_subblock_mask) replace the per-(entry, sub-block)
 // wave-level reject tests of the loop; MASK = false (GSR_BWD_MASK=0): the round-3 loop, kept for the A/B and the bit-identity test.
 #ifndef BWD_TILE_WAVES
-#define BWD_TILE_WAVES 6   // waves per SIMD the register allocation must admit (80 VGPRs): 8160 one-wave tiles at 1080p want them all
+#define BWD_TILE_WAVES 5   // waves per SIMD the register allocation must admit (<= 96 VGPRs; measured: 4, 5 and 6 within 2 %, 6 needs spills)
 #endif
 template <bool DEPTH, bool MASK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAVES, 8))) void k_render_bwd_tile(int W, int H, int grid_x, const uint2* __restrict__ ranges,
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
                                                         const float* __restrict__ dL_dinvdepth,
                                                         const uint32_t* __restrict__ slot_of_pos,
                                                         float4* __restrict__ igrad, const uint32_t* __restrict__ n_dev,
-                                                        uint32_t cap) {
+                                                        uint32_t cap, int prio1, int prio2, int prio3) {
   __shared__ float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH];   // +2: the prefetch may touch [n+1]
   if (gsr_overflowed(n_dev, cap)) return;   // grid-uniform: a truncated frame teaches nothing (gsr_common.h)
   __shared__ float4 outb[BWD1_BATCH * GSR_IGRAD_F4];                          // the batch's gradient records
@@ -538,6 +539,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
     sub_last[s] = __builtin_amdgcn_readfirstlane(m);   // deepest contributor among this sub-block's 64 pixels
   }
   const int toDo = min(len, max(max(sub_last[0], sub_last[1]), max(sub_last[2], sub_last[3])));
+  // (round 4) One wave walks one tile's list from end to end, so the launch cannot end before its LONGEST walk has: at 1080p 380
+  // entries against a mean of 203 (tools/tile_stats.py), ~2000 cycles per entry for a wave on its own and ~2700 with five
+  // waves sharing a SIMD - the 0.43 ms the launch took.  Waves with long walks therefore ask for issue priority (s_setprio):
+  // they run at close to a lone wave's pace while the short walks fill the slots they leave (-3.5 %, profiles/r04_bwd_prio_ab.txt).
+  // "Long" is judged against the frame itself: the mean n_contrib of 64 pixels sampled across the image (one load per lane) -
+  // at 1080p the mean walk is 1.35 x that figure; 1.4 / 1.65 / 1.9 x it earn priority 1 / 2 / 3.  prio1 >= 0: fixed thresholds
+  // (GSR_BWD_PRIO="t1,t2,t3", experiments); prio1 == -2: no priorities.  Scheduling only: results cannot depend on it.
+  if (prio1 != -2) {
+    int t1 = prio1, t2 = prio2, t3 = prio3;
+    if (prio1 < 0) {
+      const uint32_t sp = ((uint32_t)lane * 2654435761u + (uint32_t)tile * 40503u + 12345u) % (uint32_t)N;
+      float m = (float)n_contrib[sp];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) m += __shfl_xor(m, d, 64);
+      m *= (1.0f / 64.0f);
+      t1 = (int)(1.4f * m); t2 = (int)(1.65f * m); t3 = (int)(1.9f * m);
+    }
+    if (toDo >= t3) __builtin_amdgcn_s_setprio(3);
+    else if (toDo >= t2) __builtin_amdgcn_s_setprio(2);
+    else if (toDo >= t1) __builtin_amdgcn_s_setprio(1);
+  }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // entries beyond the deepest contributor of any pixel are never visited: their records are zeros
   for (int i = toDo + lane; i < len; i += 64) {
@@ -583,14 +605,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
     for (int i = 0; i < (BWD1_BATCH * GSR_IGRAD_F4) / 64; i++) outb[i * 64 + lane] = z4;
     __syncthreads();
     const int n = min(BWD1_BATCH, toDo - b * BWD1_BATCH);
-    float4 a = s0v[0], bb = s1v[0];
-    for (int j = 0; j < n; j++) {
+    // one list entry (record halves a, bb already in registers) against the tile's four sub-blocks; -> true if any pixel blended it
+    auto visit = [&](const int j, const float4& a, const float4& bb, const uint32_t emask) __attribute__((always_inline)) -> bool {
       const int entry1 = toDo - (b * BWD1_BATCH + j);  // 1-based list position of this entry
       bool any = false;                                // (wave-uniform)
       const float dx0 = a.x - px0, dy0 = a.y - py0;
       float4 c;
       bool have_c = false;
-      const uint32_t emask = MASK ? (uint32_t)__builtin_amdgcn_readlane((int)mymask, j) : 0xFu;   // SGPR
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         float power, G, alpha;
@@ -646,21 +667,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
         acc8 = __builtin_fmaf(dch, gp2[s], acc8);
         if (DEPTH) acc9 = __builtin_fmaf(dch, gd[s], acc9);
       }
-      // The next entry's record is requested HERE, behind the last use of this one and into the same registers (a rotating
-      // pair of register sets cost four v_mov_b64 per entry); the reduction below, or the other waves, cover the LDS latency.
-      __builtin_amdgcn_sched_barrier(0);
-      a = s0v[j + 1];
-      bb = s1v[j + 1];
-      __builtin_amdgcn_sched_barrier(0);
-      if (any) {
-        float u0, u1;
-        if (DEPTH) wave_sum10_halving(acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7, acc8, acc9, lane_bit3, u0, u1);
-        else wave_sum9_halving(acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7, acc8, lane_bit3, u0, u1);
-        float* dst = reinterpret_cast<float*>(outb) + 12 * j;
-        if (octet_lead) dst[octet_val] = u0;
-        if (u1_lead) dst[u1_slot] = u1;
-        acc0 = acc1 = acc2 = acc3 = acc4 = acc5 = acc6 = acc7 = acc8 = 0.f;
-        if (DEPTH) acc9 = 0.f;
+      return any;
+    };
+    // the wave's nine (ten) sums of entry j -> its gradient record in LDS; the sums start over
+    auto reduce = [&](const int j) __attribute__((always_inline)) {
+      float u0, u1;
+      if (DEPTH) wave_sum10_halving(acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7, acc8, acc9, lane_bit3, u0, u1);
+      else wave_sum9_halving(acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7, acc8, lane_bit3, u0, u1);
+      float* dst = reinterpret_cast<float*>(outb) + 12 * j;
+      if (octet_lead) dst[octet_val] = u0;
+      if (u1_lead) dst[u1_slot] = u1;
+      acc0 = acc1 = acc2 = acc3 = acc4 = acc5 = acc6 = acc7 = acc8 = 0.f;
+      if (DEPTH) acc9 = 0.f;
+    };
+    if (MASK) {
+      // Only the entries some live sub-block can be reached by are looked at, at all: the others (55 % of a 1080p frame's visits
+      // blend nothing - their pixels finished in front of them) cost a scalar bit scan instead of a trip through the loop.
+      uint64_t todo = BALLOT(mymask != 0u);
+      if (todo != 0ull) {
+        int j = (int)__builtin_ctzll(todo);
+        float4 a = s0v[j], bb = s1v[j];
+        while (true) {
+          todo &= todo - 1ull;
+          const int jn = todo != 0ull ? (int)__builtin_ctzll(todo) : j;
+          const uint32_t emask = (uint32_t)__builtin_amdgcn_readlane((int)mymask, j);   // SGPR
+          const bool any = visit(j, a, bb, emask);
+          // the next record is requested behind the last use of this one, into the same registers (see the unmasked loop)
+          __builtin_amdgcn_sched_barrier(0);
+          a = s0v[jn];
+          bb = s1v[jn];
+          __builtin_amdgcn_sched_barrier(0);
+          if (any) reduce(j);
+          if (todo == 0ull) break;
+          j = jn;
+        }
+      }
+    } else {
+      float4 a = s0v[0], bb = s1v[0];
+      for (int j = 0; j < n; j++) {
+        const bool any = visit(j, a, bb, 0xFu);
+        // The next entry's record is requested HERE, behind the last use of this one and into the same registers (a rotating
+        // pair of register sets cost four v_mov_b64 per entry); the reduction below, or the other waves, cover the LDS latency.
+        __builtin_amdgcn_sched_barrier(0);
+        a = s0v[j + 1];
+        bb = s1v[j + 1];
+        __builtin_amdgcn_sched_barrier(0);
+        if (any) reduce(j);
       }
     }
     __syncthreads();
@@ -701,10 +753,15 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
   const char* mk = getenv("GSR_BWD_MASK");
   const bool quad = form ? !strcmp(form, "quad") : tiles < 6000;
   const bool mask = !(mk && !strcmp(mk, "0"));
+  // issue priority for long walks: thresholds from the frame itself (default), GSR_BWD_PRIO="t1,t2,t3" fixes them, "0" = none
+  int p1 = -1, p2 = -1, p3 = -1;
+  if (const char* pr = getenv("GSR_BWD_PRIO")) {
+    if (sscanf(pr, "%d,%d,%d", &p1, &p2, &p3) != 3) p1 = p2 = p3 = -2;
+  }
   if (!quad || (form && !strcmp(form, "tile"))) {
 #define GSR_BWD_TILE_LAUNCH(D, M)                                                                                          \
   GSR_LAUNCH("render_bwd", (k_render_bwd_tile<D, M>), dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height, grid_x, \
-             ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap)
+             ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3)
     if (dL_dinvdepth) {
       if (mask) GSR_BWD_TILE_LAUNCH(true, true); else GSR_BWD_TILE_LAUNCH(true, false);
     } else {

@@ -5,6 +5,8 @@
 // Both are HBM-bound integer work; the design rules are coalesced 4-B/lane streams, LDS histograms,
 // wave64 ballots for stable ranking, and no inter-workgroup hand-offs (each pass is reduce -> scan ->
 // scatter with kernel boundaries as the only grid-wide synchronisation).
+#include <stdlib.h>
+
 #include "gsr_common.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ hist /* this pass: [256] */,
                                                     uint32_t* __restrict__ ticket, uint32_t* lookback /* [chunks][256] */,
                                                     size_t n_max, const uint32_t* __restrict__ n_dev, int shift,
-                                                    uint32_t mask) {
+                                                    uint32_t mask, uint32_t* __restrict__ fail_flags, uint32_t force_timeout) {
   __shared__ uint32_t wave_run[4][GSR_RADIX_SIZE];  // phase 1: keys of (wave, digit) seen so far; phase 2: the wave's base
   __shared__ uint32_t lstart[GSR_RADIX_SIZE];       // first local (sorted) position of each digit
   __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
@@ -363,9 +365,14 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
         }
         p -= used;                    // the first word not yet published (if any) heads the next window
         if (!done && used < GSR_LB_WINDOW) {
-          // (bounded, like every spin should be: ~1 s; a time-out can only mean a broken protocol - it leaves a mark in
-          // the word behind the tickets, gives this chunk a wrong base and lets the grid drain instead of hanging the GPU)
-          if (++spins > (1u << 20)) { ticket[GSR_RADIX_MAX_PASSES] = 0xDEADu; break; }
+          // (bounded, like every spin should be: ~1 s; a time-out can only mean a broken protocol - it gives this chunk a
+          // wrong base and lets the grid drain instead of hanging the GPU, leaves a mark in the word behind the tickets and
+          // raises GSR_STATUS_SORT_TIMEOUT in the frame's status word, which the host reads: a mis-sorted frame is REPORTED)
+          if (++spins > (1u << 20)) {
+            ticket[GSR_RADIX_MAX_PASSES] = 0xDEADu;
+            if (fail_flags) atomicOr(fail_flags, GSR_STATUS_SORT_TIMEOUT);
+            break;
+          }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -373,6 +380,12 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
                          __HIP_MEMORY_SCOPE_AGENT);
     }
     gbase[tid] = digit_start + excl;
+    // test hook (GSR_TEST_FORCE_LOOKBACK_TIMEOUT=1, tests/test_sort_gpu.py): behave as if this chunk's wait had timed out -
+    // the mark and the status bit, without the second of spinning and without touching the sort's result
+    if (force_timeout && chunk == 0 && tid == 0) {
+      ticket[GSR_RADIX_MAX_PASSES] = 0xDEADu;
+      if (fail_flags) atomicOr(fail_flags, GSR_STATUS_SORT_TIMEOUT);
+    }
   }
   __syncthreads();
   uint32_t gpos[SUBTILES];
@@ -414,8 +427,10 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
 
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
                          int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0, uint32_t* w1, const uint32_t* n_dev,
-                         bool head_zeroed) {
+                         bool head_zeroed, uint32_t* fail_flags) {
   if (n == 0 || bits <= 0) return 0;
+  const char* force_env = getenv("GSR_TEST_FORCE_LOOKBACK_TIMEOUT");      // (read per call: a test switches it inside one process)
+  const uint32_t force = (force_env && force_env[0] == '1') ? 1u : 0u;
   const uint32_t nblk = (uint32_t)gsr_radix_blocks(n);
   const int subtiles = gsr_radix_subtiles(n);
   const int passes = gsr_radix_passes(bits);
@@ -444,7 +459,8 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
   GSR_LAUNCH("radix_pass", (k_radix_pass<D, S>), dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,               \
              (const uint32_t*)(D ? (cur ? w1 : w0) : nullptr), ko, vo, (uint32_t*)(D ? (cur ? w0 : w1) : nullptr),      \
              (const uint32_t*)(hist + pass * GSR_RADIX_SIZE), tickets + pass,                                          \
-             lookback + (size_t)pass * nblk * GSR_RADIX_SIZE, n, n_dev, shift, mask)
+             lookback + (size_t)pass * nblk * GSR_RADIX_SIZE, n, n_dev, shift, mask, fail_flags,                       \
+             (force && pass == passes - 1) ? 1u : 0u)
     if (dual) {
       if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_PASS(true, GSR_RADIX_SUBTILES_SMALL);
       else GSR_PASS(true, GSR_RADIX_SUBTILES);

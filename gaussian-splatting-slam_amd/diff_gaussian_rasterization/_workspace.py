@@ -111,6 +111,7 @@ class Lease:
 
 WAIT_LIMIT_S = float(os.environ.get("GSR_COUNT_TIMEOUT_S", "120"))
 STATUS_PENDING = -1          # third status word (longest tile list | 0) before the device has written the frame's status
+STATUS_SORT_TIMEOUT = 1      # bit 0 of the first status word (csrc/gsr_common.h GSR_STATUS_SORT_TIMEOUT)
 
 
 class _StatusArrived:
@@ -214,6 +215,11 @@ class Pool:
             longest = int(status[2]) & 0xFFFFFFFF
             self.longest_list[key] = max(self.longest_list.get(key, 0), longest)
             self.status_free.append(status)
+            if flags & STATUS_SORT_TIMEOUT:
+                # (reference failure contract, README.md:168-171: a failing rasterizer call raises.  Without debug the kernels
+                # are fire-and-forget, so the report arrives with the frame's status, one call later.)
+                raise _C.GsrError(f"gsr: frame {ticket} (P, W, H = {key}): a radix-sort look-back wait timed out on the device "
+                                  "(inter-workgroup hand-off broken) - its tile lists, image and gradients are not to be trusted")
             if verified:        # "exact" mode: the count was looked at (and acted upon) before the forward returned
                 continue
             if (flags >> 32) & 1:

@@ -70,8 +70,10 @@ def make_gaussians(P: int, deg: int, seed: int, scale_factor: float = 0.25, box:
 
 
 def make_config(cfg: int, device="cpu", P: int | None = None, views: int | None = None,
-                W: int | None = None, H: int | None = None):
-    """-> (RawGaussians, [MiniCam], config dict).  Seeds: 1000*cfg (Gaussians), 1000*cfg+1 (cameras)."""
+                W: int | None = None, H: int | None = None, splat_scale: float = 1.0):
+    """-> (RawGaussians, [MiniCam], config dict).  Seeds: 1000*cfg (Gaussians), 1000*cfg+1 (cameras).
+    splat_scale: multiplier on the recipe's splat size (c = 0.25); 2.0 gives a compositing-heavy variant of the
+    same scene (tile instances per Gaussian ~ x3.5), not a BASELINE config."""
     c = dict(CONFIGS[cfg])
     if P is not None:
         c["P"] = P
@@ -81,6 +83,7 @@ def make_config(cfg: int, device="cpu", P: int | None = None, views: int | None 
         c["W"] = W
     if H is not None:
         c["H"] = H
-    g = make_gaussians(c["P"], c["deg"], 1000 * cfg).to(device)
+    g = make_gaussians(c["P"], c["deg"], 1000 * cfg, scale_factor=0.25 * splat_scale).to(device)
+    c["splat_scale"] = float(splat_scale)
     cams = fibonacci_cameras(c["views"], c["W"], c["H"], seed=1000 * cfg + 1, device=device)
     return g, cams, c

@@ -487,6 +487,8 @@ class Trainer:
         ws._wait_bounded(ws._StatusArrived(g["status"]), "the status of the replayed frame")
         self._graph_inflight = None
         flags, R = int(g["status"][0]), int(g["status"][1])
+        if flags & ws.STATUS_SORT_TIMEOUT:
+            raise dgr._C.GsrError("gsr: a radix-sort look-back wait timed out in the replayed frame (tile lists not to be trusted)")
         pool = ws.pool(self.model.get_xyz.device)
         pool.stats["num_rendered"] = R
         if R <= g["capacity"] and R >= 0:

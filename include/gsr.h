@@ -168,7 +168,8 @@ int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void
  *     are NO-OPS by construction (every backward kernel reads the count): zero gradients, no optimizer update, no statistics.
  *
  *   host_status: NULL or 8 words of host memory, filled asynchronously on `stream` at the END of the call's work:
- *                [0] reserved, [1] bit 0 = a prefiltered point failed the near-plane test, [2],[3] = num_rendered (lo, hi),
+ *                [0] bit 0 = a radix-sort look-back wait timed out on the device (broken inter-workgroup hand-off: the frame is
+ *                mis-sorted; with debug = 1 the call itself fails with GSR_ERR_HIP), [1] bit 0 = a prefiltered point failed the near-plane test, [2],[3] = num_rendered (lo, hi),
  *                [4] = longest tile list of the frame if it exceeds 2048 entries, else 0 (tile_local_sort only).
  *                Pinned memory (hipHostMalloc / torch pin_memory) is written by the compositing kernel itself through its
  *                device mapping; any other host memory gets a hipMemcpyAsync.  Read it after an event recorded behind this
