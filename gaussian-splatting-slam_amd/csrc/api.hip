@@ -14,8 +14,7 @@
 #include "gsr_common.h"
 
 // launchers defined in the kernel files
-void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool,
-                               bool, hipStream_t);
+void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool, bool, uint32_t*, int, hipStream_t);
 void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, bool, hipStream_t);
 void gsr_launch_adam_culled_rows(int, int, const char*, const GsrGeomLayout&, const GsrAdamArgs&, uint32_t, hipStream_t);
 int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
@@ -23,9 +22,9 @@ int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const i
                               hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
 void gsr_launch_emit(int, int, int, char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, bool, unsigned long long*,
-                     hipStream_t);
-void gsr_launch_tile_depth_sort(int, bool, const uint2*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*,
-                                uint32_t*, hipStream_t);
+                     int, hipStream_t);
+void gsr_launch_tile_depth_sort(int, bool, uint2*, const uint2*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*,
+                                uint32_t*, uint32_t*, hipStream_t);
 void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
@@ -293,7 +292,8 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
                             int32_t* radii, hipStream_t st, bool defer_color, uint32_t* host_status,
                             hipEvent_t copied /* recorded right behind the status copy, or nullptr */,
                             SideShade* shade_aside = nullptr, bool tile_local = false,
-                            unsigned long long** early_word = nullptr) {
+                            unsigned long long** early_word = nullptr,
+                            uint32_t* tile_sort_head = nullptr /* tile-local form: cleared by the projection kernel */) {
   const int P = g->P;
   const GsrGeomLayout L = gsr_geom_layout(P);
   if (!geometry_state || geometry_bytes < L.total) {
@@ -309,7 +309,8 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   static_assert(sizeof(uint32_t) == 4, "");
   if (!tile_local && (rc = gsr_check(hipMemsetAsync(meta, 0, 256 + GSR_RADIX_HEAD_WORDS * 4, st), "memset meta"))) return rc;
 
-  gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, /*block_sums=*/tile_local, st);
+  gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, /*block_sums=*/tile_local, tile_local ? tile_sort_head : nullptr,
+                            GSR_RADIX_HEAD_WORDS, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
   // (tile-local binning form: the colour pass is forked behind the emission instead - forward_render_impl - because the
   // two are both HBM-bound and slowed each other down (emission 36 -> 55 us); the tile sort and the per-tile ordering that
@@ -461,7 +462,8 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
                                float* out_color, float* out_invdepth, bool for_backward, bool shade_late,
                                hipEvent_t sh_ready, void* stream, bool tile_local = false,
                                uint32_t* host_status_late = nullptr, unsigned long long* early = nullptr,
-                               uint32_t* host_count = nullptr, hipEvent_t count_copied = nullptr) {
+                               uint32_t* host_count = nullptr, hipEvent_t count_copied = nullptr,
+                               bool sort_head_clean = false /* this call's projection kernel cleared the tile sort's head */) {
   int rc = validate(s, g);
   if (rc) return rc;
   if (num_rendered < 0 || num_rendered > 0x3FFFFFFFll) {   // the tile sort counts keys in 30-bit fields (sort_scan.hip)
@@ -488,7 +490,16 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   if (R == 0 || g->P == 0) {   // nothing to emit: every tile range is empty (otherwise the emit kernel clears them on its way)
     if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
   } else {
-    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, early, st);
+    // (round 4) tile-local form: the emission counts the tile sort's digit histograms and clears its look-back table, the sort's
+    // last pass leaves the tile ranges, the first per-tile kernel decodes them: no k_radix_hist_all, no k_finalize_bins
+    // (GSR_TILE_HIST=0: the round-3 chain, for the A/B).  The sort's head must be clear BEFORE the emission's workgroups add
+    // to it: the projection kernel of this call did that, or (re-render on another binning state) a memset here.
+    const char* th = getenv("GSR_TILE_HIST");
+    const bool fused_bins = tile_local && !(th && th[0] == '0');
+    if (fused_bins && !sort_head_clean &&
+        (rc = gsr_check(hipMemsetAsync(bin + BL.radix_tmp, 0, GSR_RADIX_HEAD_WORDS * 4, st), "memset sort head")))
+      return rc;
+    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, early, fused_bins ? tile_bits(tiles) : 0, st);
     // tile-local form: the emission kernel is where num_rendered comes into being.  A waiting caller whose pinned slot has no
     // device alias (early == nullptr) gets the status words by a copy, marked by an event
     if (tile_local && host_count && !early) {
@@ -514,16 +525,19 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
                                    (uint32_t*)(bin + BL.val_b), /*vals_iota=*/true, R, tile_bits(tiles),
                                    (uint32_t*)(bin + BL.radix_tmp), st, (uint32_t*)(bin + BL.gauss_of_slot),
                                    (uint32_t*)(bin + BL.point_list), n_dev, /*head_zeroed (by the emit kernel)=*/true,
-                                   /*fail_flags=*/(uint32_t*)(geom + GL.meta))
+                                   /*fail_flags=*/(uint32_t*)(geom + GL.meta), /*hist_counted=*/fused_bins,
+                                   fused_bins ? (uint2*)(bin + BL.ranges_enc) : nullptr)
             : gsr_radix_sort_pairs((uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
                                    (uint32_t*)(bin + BL.key_b), (uint32_t*)(bin + BL.point_list), /*vals_iota=*/false, R,
                                    tile_bits(tiles), (uint32_t*)(bin + BL.radix_tmp), st, nullptr, nullptr, n_dev, true,
-                                   (uint32_t*)(geom + GL.meta));
+                                   (uint32_t*)(geom + GL.meta), fused_bins, fused_bins ? (uint2*)(bin + BL.ranges_enc) : nullptr);
     if (where != tile_sort_result_buffer(tiles)) { gsr_set_error("internal: tile sort buffer parity"); return GSR_ERR_HIP; }
     if ((rc = debug_sync(s, st, "tile sort", (const uint32_t*)(geom + GL.meta)))) return rc;
-    const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
-    gsr_launch_finalize((uint32_t)R, n_dev, ks, bin, BL, st);
-    if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
+    if (!fused_bins) {
+      const uint32_t* ks = (const uint32_t*)(bin + (where ? BL.key_b : BL.key_a));
+      gsr_launch_finalize((uint32_t)R, n_dev, ks, bin, BL, st);
+      if ((rc = debug_sync(s, st, "finalize bins"))) return rc;
+    }
     if (tile_local) {
       // every tile orders its own list by (depth bits, id); the free halves of the tile sort's ping-pong buffers serve the
       // (slow) path for lists beyond the LDS capacity
@@ -531,7 +545,8 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
       uint32_t* free_w = (uint32_t*)(bin + (where ? BL.gauss_of_slot : BL.point_list));
       uint32_t* free_v = (uint32_t*)(bin + (for_backward ? (where ? BL.val_a : BL.val_b) : BL.val_a));
       uint32_t* slots = for_backward ? (uint32_t*)(bin + (where ? BL.val_b : BL.val_a)) : nullptr;
-      gsr_launch_tile_depth_sort(tiles, for_backward, (const uint2*)(bin + BL.ranges),
+      gsr_launch_tile_depth_sort(tiles, for_backward, (uint2*)(bin + BL.ranges),
+                                 fused_bins ? (const uint2*)(bin + BL.ranges_enc) : nullptr,
                                  (uint32_t*)(bin + point_list_offset(BL, tiles)), slots,
                                  (const uint32_t*)(geom + GL.depth_key), free_k, free_v, free_w,
                                  (uint32_t*)(geom + GL.meta), st);
@@ -603,14 +618,22 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
       ev = readback_event();
       if (!host || !ev) { gsr_set_error("hipHostMalloc / hipEventCreate failed"); return GSR_ERR_HIP; }
     }
+    // (tile-local form: the projection kernel clears the head of the tile sort's scratch in the caller's binning state, so that
+    // the emission's workgroups can add their digit counts to it)
+    uint32_t* sort_head = nullptr;
+    if (tlo && binning_state && capacity > 0) {
+      const int gx0 = (s->image_width + GSR_TILE - 1) / GSR_TILE, gy0 = (s->image_height + GSR_TILE - 1) / GSR_TILE;
+      const GsrBinLayout BL0 = gsr_bin_layout((size_t)capacity, (size_t)gx0 * gy0);
+      if (binning_bytes >= BL0.total) sort_head = (uint32_t*)((char*)binning_state + BL0.radix_tmp);
+    }
     if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late || aside != nullptr,
-                               host, ev, aside, tlo, &early)))
+                               host, ev, aside, tlo, &early, sort_head)))
       return rc;
     // (the caller's status words - flags, num_rendered and, in the tile-local form, the longest tile list meta[4] - leave at the END)
     rc = forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
                              out_color, out_invdepth, for_backward != 0, aside ? false : late,
                              aside ? aside->join : (hipEvent_t)sh_ready_event, stream, tlo, host_status, early, tlo ? host : nullptr,
-                             ev);
+                             ev, /*sort_head_clean=*/sort_head != nullptr);
     if (rc) return rc;
     if (num_rendered_out) {
       const int64_t n = wait_for_count(host, ev, early != nullptr);

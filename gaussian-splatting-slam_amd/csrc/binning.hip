@@ -33,14 +33,35 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
                                                         uint32_t* __restrict__ slot_start, int tiles,
                                                         uint2* __restrict__ ranges, uint32_t cap,
                                                         uint32_t* __restrict__ sort_head, uint32_t* __restrict__ meta,
-                                                        unsigned long long* __restrict__ early) {
+                                                        unsigned long long* __restrict__ early, int hist_bits,
+                                                        size_t lookback_words) {
   __shared__ uint32_t lkey[EMIT_WINDOW], lgid[EMIT_WINDOW];
   __shared__ uint32_t wave_tot[4];
   __shared__ unsigned long long wave_pre[4];
-  // the tile sort that follows wants its digit histograms and pass tickets zeroed (sort_scan.hip, head_zeroed)
-  if (blockIdx.x == 0)
+  __shared__ uint32_t lhist[2 * GSR_RADIX_SIZE];    // (hist_bits) digit counts of this workgroup's instances, both tile-sort passes
+  // hist_bits > 0 (round 4, tile-local form): this kernel writes every tile id anyway, so it also counts the tile sort's digit
+  // histograms (LDS, then one global add per non-zero counter into the replica blockIdx picks - gsr_common.h) and clears the
+  // sort's look-back table: no k_radix_hist_all launch.  The head (histogram replicas + tickets) was zeroed by the PROJECTION
+  // kernel, i.e. before any workgroup of this one can add to it.  hist_bits == 0: the head is zeroed here, for k_radix_hist_all.
+  const int hpasses = hist_bits > 0 ? gsr_radix_passes(hist_bits) : 0;     // (<= 2: tile ids have at most 16 bits)
+  if (hist_bits > 0) {
+    for (int i = threadIdx.x; i < 2 * GSR_RADIX_SIZE; i += 256) lhist[i] = 0u;
+    uint4* z = reinterpret_cast<uint4*>(sort_head + GSR_RADIX_HEAD_WORDS);      // look-back words of the sort's first pass
+    const size_t n4 = lookback_words >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+  } else if (blockIdx.x == 0) {
+    // the tile sort that follows wants its digit histograms and pass tickets zeroed (sort_scan.hip, head_zeroed)
     for (int i = threadIdx.x; i < GSR_RADIX_HEAD_WORDS; i += 256) sort_head[i] = 0u;
-  // the tile ranges are filled in after the tile sort (k_finalize_bins); tiles without instances keep this (0, 0)
+  }
+  auto count_digits = [&](uint32_t tile_id) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+      if (p < hpasses)
+        atomicAdd(&lhist[p * GSR_RADIX_SIZE + ((tile_id >> gsr_radix_shift(hist_bits, p)) & ((1u << gsr_radix_width(hist_bits, p)) - 1u))], 1u);
+  };
+  // the tile ranges are filled in after the tile sort (k_finalize_bins writes them / the sort's last pass takes maxima into them
+  // and k_tile_depth_sort decodes): tiles without instances keep this (0, 0)
   for (int t = blockIdx.x * 256 + threadIdx.x; t < tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);
   const int j0 = blockIdx.x * 256;
   const int j = j0 + threadIdx.x;
@@ -128,6 +149,7 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
           if (staged || off < cap) {   // (direct path) slots beyond the binning state's capacity are dropped, see below
             kdst[off - bias] = (uint32_t)(y * grid_x + x);
             gdst[off - bias] = g;
+            if (hist_bits > 0 && !staged) count_digits((uint32_t)(y * grid_x + x));
           }
           off++;
         }
@@ -138,6 +160,7 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
         if (staged || off < cap) {
           kdst[off - bias] = (uint32_t)(r.y * grid_x + r.x);
           gdst[off - bias] = 0xFFFFFFFFu;
+          if (hist_bits > 0 && !staged) count_digits((uint32_t)(r.y * grid_x + r.x));
         }
       }
     }
@@ -150,8 +173,18 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
     // form - instead of writing out of bounds.
     const uint32_t lim = slot0 < cap ? min(count, cap - slot0) : 0u;
     for (uint32_t i = threadIdx.x; i < lim; i += 256) {
-      tile_key[slot0 + i] = lkey[i];
+      const uint32_t k = lkey[i];
+      tile_key[slot0 + i] = k;
       gauss_of_slot[slot0 + i] = lgid[i];
+      if (hist_bits > 0) count_digits(k);          // exactly the keys that exist for the sort: slots below the capacity
+    }
+  }
+  if (hist_bits > 0) {
+    __syncthreads();
+    uint32_t* rep = sort_head + gsr_hist_replica((int)(blockIdx.x % GSR_HIST_REPLICAS));
+    for (int i = threadIdx.x; i < hpasses * GSR_RADIX_SIZE; i += 256) {
+      const uint32_t c = lhist[i];
+      if (c) atomicAdd(&rep[i], c);
     }
   }
 }
@@ -195,8 +228,12 @@ __global__ __launch_bounds__(256) void k_finalize_bins(uint32_t cap, const uint3
 #ifndef GSR_TLO_SPLIT
 #define GSR_TLO_SPLIT 1      // lists up to GSR_TLO_SMALL in a launch of their own with a quarter of the LDS (more tiles in flight per CU)
 #endif
-template <bool DUAL, int CAP, int ABOVE>
-__global__ __launch_bounds__(256) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
+// DECODE (the first launch over the tiles, round 4): `ranges` arrives as the tile sort's last pass left it - (~first position,
+// last position + 1) maxima, (0, 0) for a tile without instances - and leaves as [start, end) for every later reader.  Every
+// thread decodes its own copy of the pair first; thread 0's store of the decoded pair is only ever read by later kernels.
+template <bool DUAL, int CAP, int ABOVE, bool DECODE>
+__global__ __launch_bounds__(256) void k_tile_depth_sort(const uint2* __restrict__ ranges_in, uint2* __restrict__ ranges_out,
+                                                         uint32_t* __restrict__ point_list,
                                                          uint32_t* __restrict__ slot_of_pos,
                                                          const uint32_t* __restrict__ depth_key, uint32_t* __restrict__ free_a,
                                                          uint32_t* __restrict__ free_b, uint32_t* __restrict__ free_c,
@@ -211,9 +248,13 @@ __global__ __launch_bounds__(256) void k_tile_depth_sort(const uint2* __restrict
   __shared__ uint32_t wave_run[4][256];
   __shared__ uint32_t dstart[256];
   __shared__ uint32_t red[4], scan4[4];
-  const uint2 range = ranges[blockIdx.x];
-  const uint32_t x = range.x, n = range.y - range.x;
+  uint2 range = ranges_in[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (DECODE) {
+    range.x = range.y != 0u ? ~range.x : 0u;
+    if (tid == 0) ranges_out[blockIdx.x] = range;
+  }
+  const uint32_t x = range.x, n = range.y - range.x;
   if (n <= 1u || n <= (uint32_t)ABOVE) return;              // block-uniform (ABOVE: the lists another launch orders)
   if (CAP < GSR_TLO_CAP && n > (uint32_t)CAP) return;
   // longest list of this frame, for the caller's choice of binning form - only lists past half the LDS capacity report
@@ -367,39 +408,51 @@ __global__ __launch_bounds__(256) void k_tile_depth_sort(const uint2* __restrict
   }
 }
 
-void gsr_launch_tile_depth_sort(int tiles, bool dual, const uint2* ranges, uint32_t* point_list, uint32_t* slot_of_pos,
-                                const uint32_t* depth_key, uint32_t* free_a, uint32_t* free_b, uint32_t* free_c,
-                                uint32_t* meta, hipStream_t st) {
+// ranges_enc: nullptr (ranges hold [start, end) already: k_finalize_bins ran) or the encoded pairs of the sort's last pass, which
+// the first launch decodes into `ranges`
+void gsr_launch_tile_depth_sort(int tiles, bool dual, uint2* ranges, const uint2* ranges_enc, uint32_t* point_list,
+                                uint32_t* slot_of_pos, const uint32_t* depth_key, uint32_t* free_a, uint32_t* free_b,
+                                uint32_t* free_c, uint32_t* meta, hipStream_t st) {
+  const uint2* rin = ranges_enc ? ranges_enc : (const uint2*)ranges;
+#define GSR_TLO(NAME, D, CAPV, ABOVEV, DEC, RIN)                                                                         \
+  GSR_LAUNCH(NAME, (k_tile_depth_sort<D, CAPV, ABOVEV, DEC>), dim3(tiles), dim3(256), 0, st, RIN, ranges, point_list, \
+             slot_of_pos, depth_key, free_a, free_b, free_c, meta)
 #if GSR_TLO_SPLIT
   if (dual) {
-    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<true, GSR_TLO_SMALL, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
-               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
-    GSR_LAUNCH("tile_depth_sort_long", (k_tile_depth_sort<true, GSR_TLO_CAP, GSR_TLO_SMALL>), dim3(tiles), dim3(256), 0, st, ranges,
-               point_list, slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+    if (ranges_enc) GSR_TLO("tile_depth_sort", true, GSR_TLO_SMALL, 0, true, rin);
+    else GSR_TLO("tile_depth_sort", true, GSR_TLO_SMALL, 0, false, rin);
+    GSR_TLO("tile_depth_sort_long", true, GSR_TLO_CAP, GSR_TLO_SMALL, false, (const uint2*)ranges);
   } else {
-    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<false, GSR_TLO_SMALL, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
-               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
-    GSR_LAUNCH("tile_depth_sort_long", (k_tile_depth_sort<false, GSR_TLO_CAP, GSR_TLO_SMALL>), dim3(tiles), dim3(256), 0, st, ranges,
-               point_list, slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+    if (ranges_enc) GSR_TLO("tile_depth_sort", false, GSR_TLO_SMALL, 0, true, rin);
+    else GSR_TLO("tile_depth_sort", false, GSR_TLO_SMALL, 0, false, rin);
+    GSR_TLO("tile_depth_sort_long", false, GSR_TLO_CAP, GSR_TLO_SMALL, false, (const uint2*)ranges);
   }
 #else
-  if (dual)
-    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<true, GSR_TLO_CAP, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
-               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
-  else
-    GSR_LAUNCH("tile_depth_sort", (k_tile_depth_sort<false, GSR_TLO_CAP, 0>), dim3(tiles), dim3(256), 0, st, ranges, point_list,
-               slot_of_pos, depth_key, free_a, free_b, free_c, meta);
+  if (dual) {
+    if (ranges_enc) GSR_TLO("tile_depth_sort", true, GSR_TLO_CAP, 0, true, rin);
+    else GSR_TLO("tile_depth_sort", true, GSR_TLO_CAP, 0, false, rin);
+  } else {
+    if (ranges_enc) GSR_TLO("tile_depth_sort", false, GSR_TLO_CAP, 0, true, rin);
+    else GSR_TLO("tile_depth_sort", false, GSR_TLO_CAP, 0, false, rin);
+  }
 #endif
+#undef GSR_TLO
 }
 
+// count_hist_bits > 0 (tile-local form, sort head zeroed by the projection kernel): the emission also counts the tile sort's
+// digit histograms and clears its look-back table; the encoded tile ranges (BL.ranges_enc) are what it zero-initialises then
 void gsr_launch_emit(int P, int grid_x, int tiles, char* geom, const GsrGeomLayout& GL, char* bin,
-                     const GsrBinLayout& BL, uint32_t cap, bool index_order, unsigned long long* early, hipStream_t st) {
+                     const GsrBinLayout& BL, uint32_t cap, bool index_order, unsigned long long* early, int count_hist_bits,
+                     hipStream_t st) {
+  // (the look-back words of the sort's FIRST pass; every pass clears the next one's itself - sort_scan.hip)
+  const size_t lb_words = count_hist_bits > 0 ? (size_t)gsr_radix_blocks(cap) * GSR_RADIX_SIZE : 0;
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
              index_order ? (const uint32_t*)nullptr : (const uint32_t*)(geom + GL.order), (const uint32_t*)(geom + GL.offsets),
              (const uint32_t*)(geom + GL.tiles_touched),
              (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
-             (uint32_t*)(geom + GL.slot_start), tiles, (uint2*)(bin + BL.ranges), cap, (uint32_t*)(bin + BL.radix_tmp),
-             (uint32_t*)(geom + GL.meta), index_order ? early : (unsigned long long*)nullptr);
+             (uint32_t*)(geom + GL.slot_start), tiles, (uint2*)(bin + (count_hist_bits > 0 ? BL.ranges_enc : BL.ranges)), cap,
+             (uint32_t*)(bin + BL.radix_tmp), (uint32_t*)(geom + GL.meta),
+             index_order ? early : (unsigned long long*)nullptr, count_hist_bits, lb_words);
 }
 
 void gsr_launch_finalize(uint32_t cap, const uint32_t* n_dev, const uint32_t* tile_sorted, char* bin,

@@ -53,6 +53,8 @@ struct GsrBinLayout {
   size_t gauss_of_slot;  // u32[R] Gaussian id of each emission slot; second payload of the tile sort, ping-pongs with
   size_t point_list;     // u32[R] -> Gaussian ids sorted by (tile, depth, id) end up in ONE of the two (pass parity)
   size_t ranges;         // uint2[tiles]
+  size_t ranges_enc;     // uint2[tiles]: (~first position, last position + 1) by atomicMax from the tile sort's last pass
+  //                        (tile-local binning form), decoded into `ranges` by k_tile_depth_sort
   size_t scan_tmp;
   size_t radix_tmp;
   size_t total;
@@ -105,9 +107,20 @@ static inline __host__ __device__ int gsr_radix_shift(int bits, int pass) {
   const int p = gsr_radix_passes(bits), q = bits / p, r = bits - q * p;
   return pass * q + (pass < r ? pass : r);
 }
-#define GSR_RADIX_HEAD_WORDS (GSR_RADIX_MAX_PASSES * GSR_RADIX_SIZE + 64)   // digit histograms of every pass + pass tickets
+// Head of a sort's scratch: digit histograms of every pass + pass tickets, then GSR_HIST_REPLICAS - 1 further copies of the
+// histogram block.  A sort whose histograms are counted by MANY workgroups (round 4: the tile sort's, by k_emit_instances, 3900
+// workgroups at 1 M Gaussians) spreads its adds over the replicas by workgroup index - adds to ONE address serialise at ~15 ns -
+// and k_radix_pass sums the replicas; the classic path (k_radix_hist_all, <= 256 workgroups) fills replica 0 only.
+#ifndef GSR_HIST_REPLICAS
+#define GSR_HIST_REPLICAS 8
+#endif
+#define GSR_RADIX_HIST_WORDS (GSR_RADIX_MAX_PASSES * GSR_RADIX_SIZE)
+#define GSR_RADIX_HEAD_WORDS (GSR_RADIX_HIST_WORDS + 64 + (GSR_HIST_REPLICAS - 1) * GSR_RADIX_HIST_WORDS)
+static inline __host__ __device__ size_t gsr_hist_replica(int r) {     // word offset of histogram replica r inside the head
+  return r == 0 ? (size_t)0 : (size_t)GSR_RADIX_HIST_WORDS + 64 + (size_t)(r - 1) * GSR_RADIX_HIST_WORDS;
+}
 static inline size_t gsr_radix_tmp_elems(size_t n) {
-  // [histograms + tickets][look-back words: passes x chunks x 256]
+  // [histograms + tickets + histogram replicas][look-back words: passes x chunks x 256]
   return GSR_RADIX_HEAD_WORDS + (size_t)GSR_RADIX_MAX_PASSES * gsr_radix_blocks(n) * GSR_RADIX_SIZE;
 }
 
@@ -144,6 +157,7 @@ static inline GsrBinLayout gsr_bin_layout(size_t R, size_t tiles) {
   L.gauss_of_slot = o; o += gsr_align(R * 4);
   L.point_list = o;    o += gsr_align(R * 4);
   L.ranges = o;        o += gsr_align(tiles * 8);
+  L.ranges_enc = o;    o += gsr_align(tiles * 8);
   L.scan_tmp = o;      o += gsr_align(gsr_scan_tmp_elems(R) * 4);
   L.radix_tmp = o;     o += gsr_align(gsr_radix_tmp_elems(R) * 4);
   L.total = o;
@@ -220,7 +234,11 @@ void gsr_scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t* out, size_
 // caller that does not know the count on the host: gsr_forward_async).
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
                          int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0 = nullptr, uint32_t* w1 = nullptr,
-                         const uint32_t* n_dev = nullptr, bool head_zeroed = false, uint32_t* fail_flags = nullptr);
+                         const uint32_t* n_dev = nullptr, bool head_zeroed = false, uint32_t* fail_flags = nullptr,
+                         bool hist_counted = false, uint2* ranges_enc = nullptr);
+// hist_counted: an earlier kernel has counted every pass's digits into the head's replicas and zeroed the look-back table
+// (k_emit_instances for the tile sort): no k_radix_hist_all launch.  ranges_enc: the LAST pass also leaves, per key value t
+// (= tile id), (~first, last + 1) of its run of sorted positions in ranges_enc[t] by atomicMax (zero-initialised by the caller).
 // fail_flags: the frame's first status word (geometry state meta[0], handed to the host as status word 0): a look-back wait that
 // times out (a broken hand-off protocol: the pass then goes on with a WRONG base, the grid drains, the frame is mis-sorted) ORs
 // GSR_STATUS_SORT_TIMEOUT into it, so the failure reaches the caller instead of staying a mark in device memory.

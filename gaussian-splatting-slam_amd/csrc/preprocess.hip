@@ -261,8 +261,13 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     int defer_color, int raw_act, int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
     uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
     float4* __restrict__ bin_rec,
-    uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta, uint32_t* __restrict__ block_sums) {
+    uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta, uint32_t* __restrict__ block_sums,
+    uint32_t* __restrict__ zero_words, int n_zero_words) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+  // (round 4) the head of the tile sort's scratch - histogram replicas + pass tickets - is cleared HERE, one kernel ahead of
+  // k_emit_instances, whose workgroups all add their digit counts to it (binning.hip)
+  if (zero_words && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n_zero_words; i += 256) zero_words[i] = 0u;
   __shared__ int32_t need_sh[256];     // STAGE: which SH rows of this workgroup will be evaluated
   __shared__ uint32_t tile_sum[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1205,7 +1210,8 @@ void gsr_launch_shade(const gsr_settings* s, const gsr_gaussians* g, char* geom,
 // block_sums: the tile-local binning form's per-workgroup instance totals go to the head of the (otherwise unused) `offsets`
 // array: [0, nb) totals, [nb, 2 nb) start slots, nb = ceil(P / 256)
 void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, int32_t* radii, char* geom,
-                               const GsrGeomLayout& L, bool defer_color, bool block_sums, hipStream_t st) {
+                               const GsrGeomLayout& L, bool defer_color, bool block_sums, uint32_t* zero_words,
+                               int n_zero_words, hipStream_t st) {
   const int P = g->P;
   size_t lds = 0;
   const bool stage = !defer_color && can_stage_sh(s, g, &lds);
@@ -1216,7 +1222,7 @@ void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, in
       (float4*)(geom + L.rec),                                                                                       \
       (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles_touched),              \
       (ushort4*)(geom + L.rect), (float4*)(geom + L.bin_rec), (uint8_t*)(geom + L.clamped), (uint32_t*)(geom + L.meta), \
-      block_sums ? (uint32_t*)(geom + L.offsets) : (uint32_t*)nullptr
+      block_sums ? (uint32_t*)(geom + L.offsets) : (uint32_t*)nullptr, zero_words, n_zero_words
   if (stage)
     GSR_LAUNCH("preprocess_fwd", k_preprocess_fwd<true>, dim3((P + 255) / 256), dim3(256), lds, st, GSR_PRE_FWD_ARGS);
   else

@@ -105,6 +105,70 @@ __device__ __forceinline__ void wave_sum9_halving(float v0, float v1, float v2, 
   u1 = b;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// (round 4) The same trees on values kept as register PAIRS (P0 = (v0, v1), P1 = (v2, v3), P2 = (v4, v5), P3 = (v6, v7)): the
+// swap partners are chosen so that the adds behind each swap stage act on whole pairs - v_pk_add_f32, one instruction for
+// two sums (packed fp32 runs at the rate of plain fp32 on this part) - 3 adds instead of 6.  Which value shares a register with
+// which does not enter any value's own summation tree (lanes l + l^32, rows r + r^1, lanes l + l^8, then the octet), so every
+// total has the bits of the unpacked tree; only the octet a total ends up in differs: octet o holds value
+// {0,1,4,5,2,3,6,7}[o] = o with bits 1 and 2 exchanged (GSR_OCTET_VALUE_PK).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float gsr_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ gsr_f2 swap32_add_pk(gsr_f2 p, gsr_f2 q) {   // -> ([p.x | q.x], [p.y | q.y]) half-wave sums
+  const gsr_u2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(p.x), __float_as_uint(q.x), false, false);
+  const gsr_u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(p.y), __float_as_uint(q.y), false, false);
+  const gsr_f2 lo = {__uint_as_float(a.x), __uint_as_float(b.x)}, hi = {__uint_as_float(a.y), __uint_as_float(b.y)};
+  return lo + hi;
+}
+__device__ __forceinline__ gsr_f2 swap16_add_pk(gsr_f2 p, gsr_f2 q) {
+  const gsr_u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(p.x), __float_as_uint(q.x), false, false);
+  const gsr_u2 b = __builtin_amdgcn_permlane16_swap(__float_as_uint(p.y), __float_as_uint(q.y), false, false);
+  const gsr_f2 lo = {__uint_as_float(a.x), __uint_as_float(b.x)}, hi = {__uint_as_float(a.y), __uint_as_float(b.y)};
+  return lo + hi;
+}
+#define GSR_OCTET_VALUE_PK(o) (((o) & 1) | (((o) & 2) << 1) | (((o) & 4) >> 1))
+
+__device__ __forceinline__ void wave_sum9_halving_pk(gsr_f2 P0, gsr_f2 P1, gsr_f2 P2, gsr_f2 P3, float v8, bool lane_bit3,
+                                                     float& u0, float& u1) {
+  const gsr_f2 R0 = swap32_add_pk(P0, P1), R1 = swap32_add_pk(P2, P3);   // R0 = ([v0|v2], [v1|v3]), R1 = ([v4|v6], [v5|v7])
+  const gsr_f2 S = swap16_add_pk(R0, R1);                                // rows: S.x = [v0,v4,v2,v6], S.y = [v1,v5,v3,v7]
+  const float keep = lane_bit3 ? S.y : S.x;
+  const float send = lane_bit3 ? S.x : S.y;
+  float a = keep + dpp_get<0x128>(send);   // row_ror:8
+  float b = v8 + dpp_get<0xB1>(v8);        // the lone ninth value: the same DPP butterfly as wave_sum9_halving
+  a += dpp_get<0xB1>(a);
+  b += dpp_get<0x4E>(b);
+  a += dpp_get<0x4E>(a);
+  b += dpp_get<0x141>(b);
+  a += dpp_get<0x141>(a);
+  b += dpp_get<0x140>(b);
+  b += dpp_get<0x142>(b);
+  b += dpp_get<0x143>(b);
+  u0 = a;
+  u1 = b;
+}
+
+__device__ __forceinline__ void wave_sum10_halving_pk(gsr_f2 P0, gsr_f2 P1, gsr_f2 P2, gsr_f2 P3, gsr_f2 P4, bool lane_bit3,
+                                                      float& u0, float& u1) {
+  const gsr_f2 R0 = swap32_add_pk(P0, P1), R1 = swap32_add_pk(P2, P3);
+  const float r4 = swap32_add(P4.x, P4.y);                               // [v8 | v9]
+  const gsr_f2 S = swap16_add_pk(R0, R1);
+  const float s2 = swap16_add(r4, 0.0f);                                 // rows [v8, 0, v9, 0]
+  const float keep = lane_bit3 ? S.y : S.x;
+  const float send = lane_bit3 ? S.x : S.y;
+  float a = keep + dpp_get<0x128>(send);
+  float b = s2 + dpp_get<0x128>(s2);
+  a += dpp_get<0xB1>(a);
+  b += dpp_get<0xB1>(b);
+  a += dpp_get<0x4E>(a);
+  b += dpp_get<0x4E>(b);
+  a += dpp_get<0x141>(a);
+  b += dpp_get<0x141>(b);
+  u0 = a;
+  u1 = b;
+}
+
 // test hook (tests/test_parity_gpu.py::test_wave_reduction_primitive): in[10][64] -> out[0..9] (ten-value tree) and
 // out[10..18] (nine-value tree on rows 0..8) through the same store patterns the render backward uses
 __global__ void k_debug_wave_reduce(const float* __restrict__ in, float* __restrict__ out) {
@@ -127,6 +191,25 @@ __global__ void k_debug_wave_reduce(const float* __restrict__ in, float* __restr
 extern "C" int gsr_debug_wave_reduce(const float* in640, float* out20, void* stream) {
   hipLaunchKernelGGL(k_debug_wave_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, in640, out20);
   return gsr_launch_status("debug wave reduce");
+}
+
+// the packed-pair trees through the store pattern of k_render_bwd_tile<., MASK = true>: same in / out layout as above
+__global__ void k_debug_wave_reduce_pk(const float* __restrict__ in, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  float u0, u1;
+  auto P = [&](int i) { return gsr_f2{in[(2 * i) * 64 + lane], in[(2 * i + 1) * 64 + lane]}; };
+  wave_sum10_halving_pk(P(0), P(1), P(2), P(3), P(4), (lane & 8) != 0, u0, u1);
+  const int val = GSR_OCTET_VALUE_PK(lane >> 3);
+  if ((lane & 7) == 0) out[val] = u0;
+  if ((lane & 31) == 0) out[8 + (lane >> 5)] = u1;
+  wave_sum9_halving_pk(P(0), P(1), P(2), P(3), in[8 * 64 + lane], (lane & 8) != 0, u0, u1);
+  if ((lane & 7) == 0) out[10 + val] = u0;
+  if (lane == 63) out[18] = u1;
+}
+
+extern "C" int gsr_debug_wave_reduce_pk(const float* in640, float* out20, void* stream) {
+  hipLaunchKernelGGL(k_debug_wave_reduce_pk, dim3(1), dim3(64), 0, (hipStream_t)stream, in640, out20);
+  return gsr_launch_status("debug wave reduce (packed)");
 }
 
 #ifndef FWD_BATCH
@@ -489,6 +572,9 @@ __device__ __forceinline__ uint32_t gsr_subblock_mask(const float4& r0, const fl
 #endif
 // MASK = true (round 4, the default): sub-block masks from the staging step (gsr_subblock_mask) replace the per-(entry, sub-block)
 // wave-level reject tests of the loop; MASK = false (GSR_BWD_MASK=0): the round-3 loop, kept for the A/B and the bit-identity test.
+#ifndef BWD_LDS_REDUCE
+#define BWD_LDS_REDUCE 0   // measured out: 0.440 ms against 0.416 for the swap tree at C3 (profiles/r04_bwd_lds_reduce_ab.txt)
+#endif
 #ifndef BWD_TILE_WAVES
 #define BWD_TILE_WAVES 5   // waves per SIMD the register allocation must admit (<= 96 VGPRs; measured: 4, 5 and 6 within 2 %, 6 needs spills)
 #endif
@@ -506,6 +592,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
   __shared__ float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH];   // +2: the prefetch may touch [n+1]
   if (gsr_overflowed(n_dev, cap)) return;   // grid-uniform: a truncated frame teaches nothing (gsr_common.h)
   __shared__ float4 outb[BWD1_BATCH * GSR_IGRAD_F4];                          // the batch's gradient records
+#if BWD_LDS_REDUCE
+  // The first two stages of the halving tree (lanes l + l^32, rows r + r^1: six v_permlane swaps at 3.2 x the price of a plain
+  // VALU instruction) through LDS instead: every lane stores its sums ([value][lane], rows 80 floats apart: two lanes per bank,
+  // the minimum for 64 lanes), lane (row q, column c) reads the four rows' entries of values q and 4 + q at column c and adds them
+  // in the tree's own order, (x0 + x2) + (x1 + x3) - the same bits - and the remaining stages run as before.  The reads are
+  // issued at once and consumed after the NEXT entry's visit, so their latency hides behind it.
+  __shared__ float redbuf[(MASK ? 10 : 1) * 80];
+#endif
   const int tile = blockIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int lane = threadIdx.x;
@@ -573,8 +667,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
   const bool u1_lead = DEPTH ? (lane & 31) == 0 : lane == 63;
   const int u1_slot = DEPTH ? 8 + (lane >> 5) : 8;
   const int octet_val = (((lane >> 3) & 1) << 2) | ((lane >> 3) & 2) | (((lane >> 3) & 4) >> 2);
+  const int octet_val_pk = GSR_OCTET_VALUE_PK(lane >> 3);   // (packed-pair trees: another value order over the octets)
+  const int octet_val_lds = (((lane >> 3) & 1) << 2) | (lane >> 4);   // (LDS form: row q holds values q | 4 + q)
+  (void)octet_val_pk; (void)octet_val_lds;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f, acc5 = 0.f, acc6 = 0.f, acc7 = 0.f, acc8 = 0.f,
         acc9 = 0.f;
+  // MASK form: the same sums as register PAIRS (A01 = (acc0, acc1) ...): v_pk_fma_f32 / v_pk_mul_f32 do two of the body's
+  // accumulations per instruction and v_pk_add_f32 two of the reduction's adds, with the very operations (and contractions) of the
+  // scalar loop per component, so the bits do not change
+  gsr_f2 A01 = {0.f, 0.f}, A23 = {0.f, 0.f}, A45 = {0.f, 0.f}, A67 = {0.f, 0.f}, A89 = {0.f, 0.f};
+  gsr_f2 gp01[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) gp01[s] = gsr_f2{gp0[s], gp1[s]};
 
   const int rounds = (toDo + BWD1_BATCH - 1) / BWD1_BATCH;
   for (int b = 0; b < rounds; b++) {
@@ -655,26 +759,105 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
         // v5 = this pixel's dL/dopacity_eff; the geometry moments are taken of v5, not of g = opacity_eff v5 = dL/dpower: the
         // factor is wave-uniform and is applied once per Gaussian, after the sum over its instances (k_preprocess_bwd)
         const float v5 = G_e * dL_dalpha;
-        const float t0 = v5 * dx, t1 = v5 * dy;
-        acc0 += t0;
-        acc1 += t1;
-        acc2 = __builtin_fmaf(t0, dx, acc2);
-        acc3 = __builtin_fmaf(t0, dy, acc3);
-        acc4 = __builtin_fmaf(t1, dy, acc4);
-        acc5 += v5;
-        acc6 = __builtin_fmaf(dch, gp0[s], acc6);
-        acc7 = __builtin_fmaf(dch, gp1[s], acc7);
-        acc8 = __builtin_fmaf(dch, gp2[s], acc8);
-        if (DEPTH) acc9 = __builtin_fmaf(dch, gd[s], acc9);
+        if (MASK) {
+          // per component exactly what the scalar branch below compiles to: acc0 / acc1 = fma(d, v5, acc) (the compiler
+          // contracts `acc += v5 * d`), t = v5 * d, acc2 / acc3 = fma(t0, d, acc), acc5 = fma(G_e, dL/dalpha, acc5)
+          const gsr_f2 dxy = {dx, dy}, v55 = {v5, v5};
+          A01 = __builtin_elementwise_fma(dxy, v55, A01);
+          const gsr_f2 t01 = v55 * dxy;
+          A23 = __builtin_elementwise_fma(gsr_f2{t01.x, t01.x}, dxy, A23);
+          A45.x = __builtin_fmaf(t01.y, dy, A45.x);
+          A45.y = __builtin_fmaf(G_e, dL_dalpha, A45.y);
+          A67 = __builtin_elementwise_fma(gsr_f2{dch, dch}, gp01[s], A67);
+          A89.x = __builtin_fmaf(dch, gp2[s], A89.x);
+          if (DEPTH) A89.y = __builtin_fmaf(dch, gd[s], A89.y);
+        } else {
+          const float t0 = v5 * dx, t1 = v5 * dy;
+          acc0 += t0;
+          acc1 += t1;
+          acc2 = __builtin_fmaf(t0, dx, acc2);
+          acc3 = __builtin_fmaf(t0, dy, acc3);
+          acc4 = __builtin_fmaf(t1, dy, acc4);
+          acc5 += v5;
+          acc6 = __builtin_fmaf(dch, gp0[s], acc6);
+          acc7 = __builtin_fmaf(dch, gp1[s], acc7);
+          acc8 = __builtin_fmaf(dch, gp2[s], acc8);
+          if (DEPTH) acc9 = __builtin_fmaf(dch, gd[s], acc9);
+        }
       }
       return any;
     };
     // the wave's nine (ten) sums of entry j -> its gradient record in LDS; the sums start over
+#if BWD_LDS_REDUCE
+    // (MASK form) pending reduction: the eight partial rows read back from LDS, the ninth (tenth) value's butterfly, the entry
+    float px0 = 0.f, px1 = 0.f, px2 = 0.f, px3 = 0.f, py0 = 0.f, py1 = 0.f, py2 = 0.f, py3 = 0.f, pz0 = 0.f, pz1 = 0.f, pz2 = 0.f,
+          pz3 = 0.f, pb = 0.f;
+    int pend_j = -1;                                     // (wave-uniform)
+    auto consume = [&]() __attribute__((always_inline)) {
+      if (pend_j < 0) return;
+      const float s0 = (px0 + px2) + (px1 + px3);        // value q  at column c: (lane + lane^32) + the same of row r^1
+      const float s1 = (py0 + py2) + (py1 + py3);        // value 4 + q
+      const float keep = lane_bit3 ? s1 : s0;
+      const float send = lane_bit3 ? s0 : s1;
+      float a = keep + dpp_get<0x128>(send);             // row_ror:8
+      a += dpp_get<0xB1>(a);
+      a += dpp_get<0x4E>(a);
+      a += dpp_get<0x141>(a);
+      float b = pb;
+      if (DEPTH) {                                       // rows [v8, 0, v9, 0] as in wave_sum10_halving
+        const float s2 = (pz0 + pz2) + (pz1 + pz3);
+        b = s2 + dpp_get<0x128>(s2);
+        b += dpp_get<0xB1>(b);
+        b += dpp_get<0x4E>(b);
+        b += dpp_get<0x141>(b);
+      }
+      float* dst = reinterpret_cast<float*>(outb) + 12 * pend_j;
+      if (octet_lead) dst[octet_val_lds] = a;
+      if (u1_lead) dst[u1_slot] = b;
+      pend_j = -1;
+    };
+#endif
     auto reduce = [&](const int j) __attribute__((always_inline)) {
       float u0, u1;
+      float* dst = reinterpret_cast<float*>(outb) + 12 * j;
+      if (MASK) {
+#if BWD_LDS_REDUCE
+        float* rb = redbuf + lane;
+        rb[0 * 80] = A01.x; rb[1 * 80] = A01.y; rb[2 * 80] = A23.x; rb[3 * 80] = A23.y;
+        rb[4 * 80] = A45.x; rb[5 * 80] = A45.y; rb[6 * 80] = A67.x; rb[7 * 80] = A67.y;
+        if (DEPTH) { rb[8 * 80] = A89.x; rb[9 * 80] = A89.y; }
+        const int q = lane >> 4, c = lane & 15;
+        const float* r0 = redbuf + q * 80 + c;
+        const float* r1 = redbuf + (4 + q) * 80 + c;
+        px0 = r0[0]; px1 = r0[16]; px2 = r0[32]; px3 = r0[48];
+        py0 = r1[0]; py1 = r1[16]; py2 = r1[32]; py3 = r1[48];
+        if (DEPTH) {
+          // rows 0 / 2 take values 8 / 9, rows 1 / 3 nothing (their lanes add zeros, as the swap tree's `swap16_add(r4, 0)` does)
+          const float* r2 = redbuf + (8 + (q >> 1)) * 80 + c;
+          const bool on = (q & 1) == 0;
+          pz0 = on ? r2[0] : 0.f; pz1 = on ? r2[16] : 0.f; pz2 = on ? r2[32] : 0.f; pz3 = on ? r2[48] : 0.f;
+        } else {
+          float b = A89.x + dpp_get<0xB1>(A89.x);        // the lone ninth value: the DPP butterfly of wave_sum9_halving
+          b += dpp_get<0x4E>(b);
+          b += dpp_get<0x141>(b);
+          b += dpp_get<0x140>(b);
+          b += dpp_get<0x142>(b);
+          b += dpp_get<0x143>(b);
+          pb = b;
+        }
+        pend_j = j;
+        (void)u0; (void)u1; (void)dst;
+#else
+        if (DEPTH) wave_sum10_halving_pk(A01, A23, A45, A67, A89, lane_bit3, u0, u1);
+        else wave_sum9_halving_pk(A01, A23, A45, A67, A89.x, lane_bit3, u0, u1);
+        if (octet_lead) dst[octet_val_pk] = u0;
+        if (u1_lead) dst[u1_slot] = u1;
+#endif
+        A01 = A23 = A45 = A67 = A89 = gsr_f2{0.f, 0.f};
+        return;
+      }
       if (DEPTH) wave_sum10_halving(acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7, acc8, acc9, lane_bit3, u0, u1);
       else wave_sum9_halving(acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7, acc8, lane_bit3, u0, u1);
-      float* dst = reinterpret_cast<float*>(outb) + 12 * j;
       if (octet_lead) dst[octet_val] = u0;
       if (u1_lead) dst[u1_slot] = u1;
       acc0 = acc1 = acc2 = acc3 = acc4 = acc5 = acc6 = acc7 = acc8 = 0.f;
@@ -697,10 +880,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
           a = s0v[jn];
           bb = s1v[jn];
           __builtin_amdgcn_sched_barrier(0);
+#if BWD_LDS_REDUCE
+          consume();                 // the previous hit's sums have come back from LDS while this entry was looked at
+#endif
           if (any) reduce(j);
           if (todo == 0ull) break;
           j = jn;
         }
+#if BWD_LDS_REDUCE
+        consume();
+#endif
       }
     } else {
       float4 a = s0v[0], bb = s1v[0];
@@ -718,6 +907,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
     __syncthreads();
     // (the nine sums are zero between entries; saying so here lets their registers go free across the staging code above)
     acc0 = acc1 = acc2 = acc3 = acc4 = acc5 = acc6 = acc7 = acc8 = acc9 = 0.f;
+    A01 = A23 = A45 = A67 = A89 = gsr_f2{0.f, 0.f};
     // flush the batch: 3 float4 per entry, at the entry's emission slot (grouped per Gaussian for k_preprocess_bwd)
     for (int q = lane; q < n * GSR_IGRAD_F4; q += 64) {
       const int j = q / GSR_IGRAD_F4, part = q - j * GSR_IGRAD_F4;

@@ -221,16 +221,23 @@ __global__ __launch_bounds__(256) void k_radix_hist_all(const uint32_t* __restri
 // Stable: equal digits keep (chunk, wave, sub-tile, lane) = original order.
 // DUAL: a second 32-bit payload rides along (the tile sort carries the Gaussian id next to the emission slot, so no
 // gather by slot is needed afterwards).
-template <bool DUAL, int SUBTILES>
+// RANGES (the tile sort's last pass, tile-local binning form): the sorted keys are tile ids; every run of equal keys inside the
+// chunk's locally sorted buffer is a run of consecutive global positions, so its first / last element leave (~first, last + 1)
+// in ranges_enc[tile] by atomicMax (a tile's run may span chunks: the maxima over its pieces are its true start and end) -
+// k_tile_depth_sort decodes them: no k_finalize_bins launch.
+template <bool DUAL, int SUBTILES, bool RANGES>
 __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__ keys_in,
                                                     const uint32_t* __restrict__ vals_in,
                                                     const uint32_t* __restrict__ vals2_in,
                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                     uint32_t* __restrict__ vals2_out,
-                                                    const uint32_t* __restrict__ hist /* this pass: [256] */,
+                                                    const uint32_t* __restrict__ head /* the sort's scratch head */, int pass,
+                                                    int hist_reps /* replicas of the histograms in use (gsr_common.h) */,
                                                     uint32_t* __restrict__ ticket, uint32_t* lookback /* [chunks][256] */,
                                                     size_t n_max, const uint32_t* __restrict__ n_dev, int shift,
-                                                    uint32_t mask, uint32_t* __restrict__ fail_flags, uint32_t force_timeout) {
+                                                    uint32_t mask, uint32_t* __restrict__ fail_flags, uint32_t force_timeout,
+                                                    uint2* __restrict__ ranges_enc, uint32_t* __restrict__ zero_next,
+                                                    size_t zero_next_words) {
   __shared__ uint32_t wave_run[4][GSR_RADIX_SIZE];  // phase 1: keys of (wave, digit) seen so far; phase 2: the wave's base
   __shared__ uint32_t lstart[GSR_RADIX_SIZE];       // first local (sorted) position of each digit
   __shared__ uint32_t gbase[GSR_RADIX_SIZE];        // global position of the chunk's first key of each digit
@@ -238,16 +245,39 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
   __shared__ uint32_t lds4[4];
   __shared__ uint32_t s_chunk;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // (hist_counted sorts) the NEXT pass's look-back words are cleared by this pass - just ahead of their use, so they are still in
+  // L2 when that pass polls them - instead of by the kernel that counted the histograms
+  if (zero_next) {
+    uint4* z = reinterpret_cast<uint4*>(zero_next);
+    const size_t n4 = zero_next_words >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  // keys with digit `tid` in this pass, whole array: the sum of the histogram's replicas (a sort that fills replica 0 only leaves
+  // zeros in the others).  All loads in flight together: a loop over a run-time count made them 8 dependent L2 round trips, +5 us
+  // per pass (profiles/r04_binning_chain_ab.txt)
+  uint32_t hrep[GSR_HIST_REPLICAS];
+#pragma unroll
+  for (int r = 0; r < GSR_HIST_REPLICAS; r++) hrep[r] = head[gsr_hist_replica(r) + (size_t)pass * GSR_RADIX_SIZE + tid];
+  uint32_t hist_tid = 0;
+#pragma unroll
+  for (int r = 0; r < GSR_HIST_REPLICAS; r++) hist_tid += hrep[r];
+  (void)hist_reps;
   {
     // Every key has the same digit in this pass (e.g. the top byte of fp32 depths that span less than a factor of 4): the
     // pass is the identity permutation, so the chunk is copied straight across - no ticket, no ranking, no look-back.
     const size_t n0 = gsr_eff_n(n_dev, (uint32_t)n_max);
-    if (__syncthreads_or(hist[tid] == (uint32_t)n0 && n0 != 0)) {
+    if (__syncthreads_or(hist_tid == (uint32_t)n0 && n0 != 0)) {
       const size_t b0 = (size_t)blockIdx.x * (256 * SUBTILES);
       for (uint32_t i = tid; i < (uint32_t)(256 * SUBTILES) && b0 + i < n0; i += 256) {
-        keys_out[b0 + i] = keys_in[b0 + i];
+        const uint32_t kk = keys_in[b0 + i];
+        keys_out[b0 + i] = kk;
         vals_out[b0 + i] = vals_in ? vals_in[b0 + i] : (uint32_t)(b0 + i);
         if (DUAL) vals2_out[b0 + i] = vals2_in[b0 + i];
+        if (RANGES) {      // (the array is sorted already: neighbours in memory are neighbours in the order)
+          const size_t g = b0 + i;
+          if (g == 0 || keys_in[g - 1] != kk) atomicMax(&ranges_enc[kk].x, ~(uint32_t)g);
+          if (g + 1 == n0 || keys_in[g + 1] != kk) atomicMax(&ranges_enc[kk].y, (uint32_t)g + 1u);
+        }
       }
       return;
     }
@@ -267,7 +297,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
   uint32_t digit_start;                             // keys with a smaller digit, whole array
   {
     uint32_t tot;
-    digit_start = block_excl_scan_u32(hist[tid], &tot, lds4);
+    digit_start = block_excl_scan_u32(hist_tid, &tot, lds4);
   }
   const uint32_t count = (uint32_t)min((size_t)(256 * SUBTILES), n - base);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -398,6 +428,10 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
       const uint32_t d = (kk >> shift) & mask;
       gpos[k] = gbase[d] + (i - lstart[d]);
       keys_out[gpos[k]] = kk;
+      if (RANGES) {
+        if (i == 0 || lbuf[i - 1] != kk) atomicMax(&ranges_enc[kk].x, ~gpos[k]);
+        if (i + 1 == count || lbuf[i + 1] != kk) atomicMax(&ranges_enc[kk].y, gpos[k] + 1u);
+      }
     }
   }
   __syncthreads();
@@ -427,7 +461,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
 
 int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, bool vals_iota, size_t n,
                          int bits, uint32_t* tmp, hipStream_t st, uint32_t* w0, uint32_t* w1, const uint32_t* n_dev,
-                         bool head_zeroed, uint32_t* fail_flags) {
+                         bool head_zeroed, uint32_t* fail_flags, bool hist_counted, uint2* ranges_enc) {
   if (n == 0 || bits <= 0) return 0;
   const char* force_env = getenv("GSR_TEST_FORCE_LOOKBACK_TIMEOUT");      // (read per call: a test switches it inside one process)
   const uint32_t force = (force_env && force_env[0] == '1') ? 1u : 0u;
@@ -436,16 +470,18 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
   const int passes = gsr_radix_passes(bits);
   // tmp = [hist: MAX_PASSES x 256][tickets: 64 words][look-back: passes x chunks x 256]   (gsr_radix_tmp_elems)
   uint32_t* hist = tmp;
-  uint32_t* tickets = tmp + GSR_RADIX_MAX_PASSES * GSR_RADIX_SIZE;
+  uint32_t* tickets = tmp + GSR_RADIX_HIST_WORDS;
   uint32_t* lookback = tmp + GSR_RADIX_HEAD_WORDS;
   const size_t lb_words = (size_t)passes * nblk * GSR_RADIX_SIZE;
-  if (!head_zeroed) (void)hipMemsetAsync(tmp, 0, GSR_RADIX_HEAD_WORDS * 4, st);
+  if (!head_zeroed && !hist_counted) (void)hipMemsetAsync(tmp, 0, GSR_RADIX_HEAD_WORDS * 4, st);
   const bool dual = w0 != nullptr && w1 != nullptr;
+  const int reps = hist_counted ? GSR_HIST_REPLICAS : 1;
   // one workgroup per CU: every workgroup ends with one global add per non-zero counter, and adds to ONE address serialise
   // (~15 ns each): 128 / 256 / 512 / 1024 workgroups -> 22 / 17 / 21 / 29 us at 4.4 M keys
   const unsigned hgrid = nblk < 256u ? nblk : 256u;
-  GSR_LAUNCH("radix_hist", k_radix_hist_all, dim3(hgrid), dim3(256), 0, st, (const uint32_t*)k0, n, n_dev, bits, hist,
-             lookback, lb_words);
+  if (!hist_counted)     // (else: an earlier kernel counted the digits into the replicas and cleared the look-back table)
+    GSR_LAUNCH("radix_hist", k_radix_hist_all, dim3(hgrid), dim3(256), 0, st, (const uint32_t*)k0, n, n_dev, bits, hist,
+               lookback, lb_words);
   int cur = 0;
   for (int pass = 0; pass < passes; pass++) {
     const int shift = gsr_radix_shift(bits, pass);
@@ -455,18 +491,21 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
     uint32_t* ko = cur ? k0 : k1;
     uint32_t* vo = cur ? v0 : v1;
     const uint32_t* vin = (pass == 0 && vals_iota) ? nullptr : vi;
-#define GSR_PASS(D, S)                                                                                                 \
-  GSR_LAUNCH("radix_pass", (k_radix_pass<D, S>), dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,               \
+#define GSR_PASS(D, S, RG)                                                                                             \
+  GSR_LAUNCH("radix_pass", (k_radix_pass<D, S, RG>), dim3(nblk), dim3(256), 0, st, (const uint32_t*)ki, vin,           \
              (const uint32_t*)(D ? (cur ? w1 : w0) : nullptr), ko, vo, (uint32_t*)(D ? (cur ? w0 : w1) : nullptr),      \
-             (const uint32_t*)(hist + pass * GSR_RADIX_SIZE), tickets + pass,                                          \
+             (const uint32_t*)tmp, pass, reps, tickets + pass,                                                         \
              lookback + (size_t)pass * nblk * GSR_RADIX_SIZE, n, n_dev, shift, mask, fail_flags,                       \
-             (force && pass == passes - 1) ? 1u : 0u)
+             (force && pass == passes - 1) ? 1u : 0u, ranges_enc,                                                      \
+             (hist_counted && pass + 1 < passes) ? lookback + (size_t)(pass + 1) * nblk * GSR_RADIX_SIZE : (uint32_t*)nullptr, \
+             (size_t)nblk * GSR_RADIX_SIZE)
+    const bool rg = ranges_enc != nullptr && pass == passes - 1;
     if (dual) {
-      if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_PASS(true, GSR_RADIX_SUBTILES_SMALL);
-      else GSR_PASS(true, GSR_RADIX_SUBTILES);
+      if (subtiles == GSR_RADIX_SUBTILES_SMALL) { if (rg) GSR_PASS(true, GSR_RADIX_SUBTILES_SMALL, true); else GSR_PASS(true, GSR_RADIX_SUBTILES_SMALL, false); }
+      else { if (rg) GSR_PASS(true, GSR_RADIX_SUBTILES, true); else GSR_PASS(true, GSR_RADIX_SUBTILES, false); }
     } else {
-      if (subtiles == GSR_RADIX_SUBTILES_SMALL) GSR_PASS(false, GSR_RADIX_SUBTILES_SMALL);
-      else GSR_PASS(false, GSR_RADIX_SUBTILES);
+      if (subtiles == GSR_RADIX_SUBTILES_SMALL) { if (rg) GSR_PASS(false, GSR_RADIX_SUBTILES_SMALL, true); else GSR_PASS(false, GSR_RADIX_SUBTILES_SMALL, false); }
+      else { if (rg) GSR_PASS(false, GSR_RADIX_SUBTILES, true); else GSR_PASS(false, GSR_RADIX_SUBTILES, false); }
     }
 #undef GSR_PASS
     cur ^= 1;

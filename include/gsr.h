@@ -31,9 +31,10 @@
 extern "C" {
 #endif
 
-/* 5: gsr_fused_adam.dynamic + gsr_adam_set_dynamic (optimizer factors in device memory, for HIP-graph replay), gsr_l1_mean_*;
+/* 6: host_status word 0 bit 0 = radix-sort look-back time-out (was reserved; debug = 1 fails the call), gsr_debug_wave_reduce_pk;
+ * 5: gsr_fused_adam.dynamic + gsr_adam_set_dynamic (optimizer factors in device memory, for HIP-graph replay), gsr_l1_mean_*;
  * 4: gsr_forward_async(num_rendered_out) / gsr_forward_rerender (verified speculation), gsr_sh_rank1_*; 3: gsr_backward_adam */
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 
 enum {
   GSR_OK = 0,
@@ -264,6 +265,8 @@ int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float*
 /* test hook: 64-lane sums through the render backward's cross-lane reductions; in[10][64] -> out[20]:
  * out[0..9] = the ten-value tree, out[10..18] = the nine-value tree on rows 0..8, out[19] unused */
 int gsr_debug_wave_reduce(const float* in640, float* out20, void* stream);
+/* the same sums through the packed-pair trees (v_pk_add_f32 behind the swap stages) of k_render_bwd_tile; same layout */
+int gsr_debug_wave_reduce_pk(const float* in640, float* out20, void* stream);
 int gsr_debug_binning_views(const void* binning_state, int32_t image_width, int32_t image_height,
                             int64_t num_rendered, const uint32_t** point_list, const uint32_t** ranges);
 /* Pair evaluations of the compositing forward (SURVEY.md 8(d) "FLOP model"): pairs[2*H*W] (uint32) = per pixel, the number of

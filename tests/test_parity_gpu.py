@@ -398,11 +398,19 @@ def test_wave_reduction_primitive():
         if trial == 0:
             x = (torch.arange(640).view(10, 64) % 97).float() * (torch.arange(10).view(10, 1) + 1)
         xin = x.cuda().contiguous()
-        out = torch.zeros(20, device="cuda")
-        _C.check(lib.gsr_debug_wave_reduce(_C.ptr(xin), _C.ptr(out), _C._stream()))
-        torch.cuda.synchronize()
-        assert torch.equal(out.cpu()[:10], x.sum(dim=1)), (out.cpu(), x.sum(dim=1))        # ten-value tree
-        assert torch.equal(out.cpu()[10:19], x.sum(dim=1)[:9]), (out.cpu(), x.sum(dim=1))  # nine-value tree
+        for hook in (lib.gsr_debug_wave_reduce, lib.gsr_debug_wave_reduce_pk):      # scalar trees; packed-pair trees (round 4)
+            out = torch.zeros(20, device="cuda")
+            _C.check(hook(_C.ptr(xin), _C.ptr(out), _C._stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(out.cpu()[:10], x.sum(dim=1)), (out.cpu(), x.sum(dim=1))        # ten-value tree
+            assert torch.equal(out.cpu()[10:19], x.sum(dim=1)[:9]), (out.cpu(), x.sum(dim=1))  # nine-value tree
+    # and on arbitrary floats the packed trees give the bits of the scalar ones (the same summation tree per value)
+    x = torch.randn(10, 64, generator=gen).cuda().contiguous()
+    o1, o2 = torch.zeros(20, device="cuda"), torch.zeros(20, device="cuda")
+    _C.check(lib.gsr_debug_wave_reduce(_C.ptr(x), _C.ptr(o1), _C._stream()))
+    _C.check(lib.gsr_debug_wave_reduce_pk(_C.ptr(x), _C.ptr(o2), _C._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
 
 
 def test_config4_code_path_small():
