@@ -17,6 +17,8 @@ timeout -k 10 300 python3 bench.py $DRV --config 4 --views 4 --no-cpu-baseline >
 # BASELINE configs[4]: the preset grows 50 k -> 500 k (bench.py: --config 5 = reference schedule from iteration 100, threshold 2e-5, stop at 500 k, 2500 steps)
 timeout -k 10 400 python3 bench.py --config 5 --warmup 10 --no-cpu-baseline > $OUT/bench_c5_growth500k.json 2> $OUT/bench_c5_growth500k.err
 timeout -k 10 300 python3 bench.py --config 5 --densify --densify-from 100 --densify-grad-threshold 0.0002 --steps 2500 --warmup 10 --no-cpu-baseline > $OUT/bench_c5_reference_threshold.json 2> $OUT/bench_c5_reference_threshold.err
+# NOT a BASELINE config: C3 with twice the recipe's splat size - the compositing kernels dominate as on a real capture
+timeout -k 10 300 python3 bench.py $DRV --scale-factor 2 --no-cpu-baseline > $OUT/bench_c3_heavy.json 2> $OUT/bench_c3_heavy.err
 timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --optimizer hip > $OUT/bench_c3_adam_unfused.json 2> /dev/null
 timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --optimizer hip_sparse_fused > $OUT/bench_c3_sparse_fused.json 2> /dev/null
 timeout -k 10 200 python3 bench.py $DRV --no-cpu-baseline --forward-mode sync > $OUT/bench_c3_sync_forward.json 2> /dev/null
