@@ -212,6 +212,44 @@ extern "C" int gsr_debug_wave_reduce_pk(const float* in640, float* out20, void* 
   return gsr_launch_status("debug wave reduce (packed)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// (round 4) Sub-block masks, computed where the records are STAGED.  The lane that copies list entry e into LDS also decides,
+// for that entry, which of the tile's four 8x8 sub-blocks the Gaussian can reach at all: bit s is set unless the maximum of the
+// (concave) log2-power over the hull of sub-block s's pixel centres stays below the record's cut-off pmin' (= alpha < 1/255
+// everywhere, with the record's own margin), or every pixel of the sub-block finished in front of this entry (entry1 >
+// sub_last[s]).  64 entries are tested by 64 lanes at once (~170 VALU wave-instructions per BATCH instead of 8 VALU + two
+// ballots + two branches per (entry, sub-block) in the entry loop), and the loop reads an entry's mask into an SGPR
+// (v_readlane) and skips missed sub-blocks on the scalar unit.  The test is conservative (max over the continuous rectangle >=
+// max over its pixel centres; slack 2e-6 x the magnitude of the form's terms >> fp32 error of either evaluation; the record's
+// cut-off already lies 0.0144 below the exact alpha >= 1/255 threshold), and a sub-block that is skipped would only have added
+// exact zeros: gradients are bit-identical to the unmasked kernel (tests/test_parity_gpu.py::test_backward_subblock_masks...).
+// Max of q(d) = A' dx^2 + B' dx dy + C' dy^2 (A', C' < 0) over a box not containing 0: on one of the four edges, where q is a
+// concave parabola in the free coordinate - clamp its vertex into the edge.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gsr_clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+__device__ __forceinline__ uint32_t gsr_subblock_mask(const float4& r0, const float4& r1, float ox, float oy) {
+  const float As = r0.z, Bs = r0.w, Cs = r1.x, pmin = r1.z;
+  if (!(pmin < 1.0e30f)) return 0u;                        // padding slot: never reached
+  const float kx = -0.5f * Bs * __builtin_amdgcn_rcpf(As), ky = -0.5f * Bs * __builtin_amdgcn_rcpf(Cs);
+  const float aA = fabsf(As), aB = fabsf(Bs), aC = fabsf(Cs);
+  uint32_t m = 0u;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const float dxh = r0.x - (ox + (float)((s & 1) * 8)), dxl = dxh - 7.0f;      // d = mean - pixel over the sub-block's pixels
+    const float dyh = r0.y - (oy + (float)((s >> 1) * 8)), dyl = dyh - 7.0f;
+    auto q = [&](float dx, float dy) { return __builtin_fmaf(Cs * dy, dy, __builtin_fmaf(Bs, dy, As * dx) * dx); };
+    const float e0 = q(dxl, gsr_clampf(ky * dxl, dyl, dyh)), e1 = q(dxh, gsr_clampf(ky * dxh, dyl, dyh));
+    const float e2 = q(gsr_clampf(kx * dyl, dxl, dxh), dyl), e3 = q(gsr_clampf(kx * dyh, dxl, dxh), dyh);
+    const bool inside = dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f;
+    const float qmax = inside ? 0.0f : fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+    const float dxm = fmaxf(fabsf(dxl), fabsf(dxh)), dym = fmaxf(fabsf(dyl), fabsf(dyh));
+    const float mag = aA * dxm * dxm + aB * dxm * dym + aC * dym * dym;
+    if (qmax >= pmin - 2.0e-6f * mag) m |= 1u << s;
+  }
+  return m;
+}
+
 #ifndef FWD_BATCH
 #define FWD_BATCH 256
 #endif
@@ -219,7 +257,14 @@ extern "C" int gsr_debug_wave_reduce_pk(const float* in640, float* out20, void* 
 
 // COUNT = true: the instrumented build behind gsr_debug_count_pairs (SURVEY.md 8(d) "FLOP model": pair evaluations E); it
 // additionally counts, per pixel, the list entries evaluated while the pixel was still compositing, and writes nothing else.
-template <bool COUNT>
+// MASKED (round 4; opt-in, GSR_FWD_MASK=1 - measured SLOWER than the plain loop at C3, 0.208 against 0.179 ms: the forward stops
+// after ~200 of a tile's 532 entries, so the 256 masks of a batch are mostly computed for nothing, and the walk over set bits loses
+// the four-entry unrolled prefetch): the thread that stages entry e also computes which of the tile's
+// four 8x8 quadrants its alpha >= 1/255 ellipse can reach (gsr_subblock_mask, conservative) and leaves the four bits in LDS; every
+// wave takes the bit of ITS quadrant of all 256 staged entries with four ballots and walks only the entries whose bit is set -
+// an entry out of reach costs a scalar bit scan instead of 8 VALU + a ballot + a branch.  Entries that ARE walked take the exact
+// published test, in the published order: images, final_T and n_contrib are bit-identical.
+template <bool COUNT, bool MASKED>
 __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, const uint2* __restrict__ ranges,
                                                     const uint32_t* __restrict__ point_list,
                                                     const float4* __restrict__ rec, const float* __restrict__ bg,
@@ -229,6 +274,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
                                                     const uint32_t* __restrict__ status_src,
                                                     uint32_t* __restrict__ status_dst) {
   __shared__ float4 s0[FWD_BATCH + 6], s1[FWD_BATCH + 6], s2[FWD_BATCH];  // +6: the prefetch may touch [n+5]
+  __shared__ uint32_t smask[MASKED ? FWD_BATCH : 1];                      // (MASKED) reachable quadrants of every staged entry
   const int tile = blockIdx.x;
   // non-blocking forward: the frame's status words (flags, num_rendered, longest tile list - final since the previous
   // kernel) go straight to the caller's pinned host slot; a 32-byte hipMemcpyAsync here cost ~10 us of stream time
@@ -264,19 +310,23 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   for (int r = 0; r < rounds; r++, toDo -= FWD_BATCH) {
     if (__syncthreads_count(pxe > 1.0e14f) == 256) break;
     const uint32_t progress = range.x + (uint32_t)(r * FWD_BATCH + tid);
+    uint32_t mymask = 0u;
     if (progress < range.y) {
       const uint32_t id32 = point_list[progress];
       if (id32 != 0xFFFFFFFFu) {
         const size_t id = id32;
-        s0[tid] = rec[3 * id + 0];
-        s1[tid] = rec[3 * id + 1];
+        const float4 r0 = rec[3 * id + 0], r1 = rec[3 * id + 1];
+        s0[tid] = r0;
+        s1[tid] = r1;
         s2[tid] = rec[3 * id + 2];
+        if (MASKED) mymask = gsr_subblock_mask(r0, r1, (float)(tile_x * GSR_TILE), (float)(tile_y * GSR_TILE));
       } else {  // padding slot (see k_emit_instances): a record that can never pass the reject test
         s0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         s1[tid] = make_float4(0.f, 0.f, 3.0e38f, 0.f);
         s2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    if (MASKED) smask[tid] = mymask;
     __syncthreads();
     const int n = toDo < FWD_BATCH ? toDo : FWD_BATCH;
     // one list entry against this wave's 64 pixels
@@ -305,6 +355,28 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
         live &= ~(BALLOT(power <= 0.0f) & BALLOT(alpha >= ALPHA_MIN) & BALLOT(test_T < 0.0001f));  // quadrant saturated -> leave
       }
     };
+    if (MASKED) {
+      // this wave's quadrant bit of all staged entries (threads beyond the list staged a zero mask), then only the set bits
+      uint64_t todo[FWD_BATCH / 64];
+#pragma unroll
+      for (int k = 0; k < FWD_BATCH / 64; k++) todo[k] = BALLOT(((smask[k * 64 + lane] >> w) & 1u) != 0u);
+#pragma unroll
+      for (int k = 0; k < FWD_BATCH / 64; k++) {
+        uint64_t td = todo[k];
+        if (td == 0ull || live == 0ull) continue;
+        int j = k * 64 + (int)__builtin_ctzll(td);
+        float4 a = s0v[j], b = s1v[j];
+        while (true) {
+          td &= td - 1ull;
+          const int jn = td != 0ull ? k * 64 + (int)__builtin_ctzll(td) : j;
+          const float4 an = s0v[jn], bn = s1v[jn];      // the next record is requested before this one is worked on
+          step(a, b, j);
+          if (td == 0ull || live == 0ull) break;
+          a = an; b = bn; j = jn;
+        }
+      }
+      continue;
+    }
     // four entries per trip, records prefetched two entries ahead into rotating register sets
     float4 a0 = s0v[0], b0 = s1v[0], a1 = s0v[1], b1 = s1v[1];
     for (int j = 0; j < n && live != 0ull; j += 4) {
@@ -529,44 +601,6 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
 // 31 KB), and a sub-block the Gaussian misses still costs only the 9-instruction reject test behind a scalar skip.
 // Summation order is fixed (sub-blocks 0..3 in a lane, then the halving tree): bitwise reproducible like the first form.
 // ---------------------------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------------------------
-// (round 4) Sub-block masks, computed where the records are STAGED.  The lane that copies list entry e into LDS also decides,
-// for that entry, which of the tile's four 8x8 sub-blocks the Gaussian can reach at all: bit s is set unless the maximum of the
-// (concave) log2-power over the hull of sub-block s's pixel centres stays below the record's cut-off pmin' (= alpha < 1/255
-// everywhere, with the record's own margin), or every pixel of the sub-block finished in front of this entry (entry1 >
-// sub_last[s]).  64 entries are tested by 64 lanes at once (~170 VALU wave-instructions per BATCH instead of 8 VALU + two
-// ballots + two branches per (entry, sub-block) in the entry loop), and the loop reads an entry's mask into an SGPR
-// (v_readlane) and skips missed sub-blocks on the scalar unit.  The test is conservative (max over the continuous rectangle >=
-// max over its pixel centres; slack 2e-6 x the magnitude of the form's terms >> fp32 error of either evaluation; the record's
-// cut-off already lies 0.0144 below the exact alpha >= 1/255 threshold), and a sub-block that is skipped would only have added
-// exact zeros: gradients are bit-identical to the unmasked kernel (tests/test_parity_gpu.py::test_backward_subblock_masks...).
-// Max of q(d) = A' dx^2 + B' dx dy + C' dy^2 (A', C' < 0) over a box not containing 0: on one of the four edges, where q is a
-// concave parabola in the free coordinate - clamp its vertex into the edge.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gsr_clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
-
-__device__ __forceinline__ uint32_t gsr_subblock_mask(const float4& r0, const float4& r1, float ox, float oy) {
-  const float As = r0.z, Bs = r0.w, Cs = r1.x, pmin = r1.z;
-  if (!(pmin < 1.0e30f)) return 0u;                        // padding slot: never reached
-  const float kx = -0.5f * Bs * __builtin_amdgcn_rcpf(As), ky = -0.5f * Bs * __builtin_amdgcn_rcpf(Cs);
-  const float aA = fabsf(As), aB = fabsf(Bs), aC = fabsf(Cs);
-  uint32_t m = 0u;
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const float dxh = r0.x - (ox + (float)((s & 1) * 8)), dxl = dxh - 7.0f;      // d = mean - pixel over the sub-block's pixels
-    const float dyh = r0.y - (oy + (float)((s >> 1) * 8)), dyl = dyh - 7.0f;
-    auto q = [&](float dx, float dy) { return __builtin_fmaf(Cs * dy, dy, __builtin_fmaf(Bs, dy, As * dx) * dx); };
-    const float e0 = q(dxl, gsr_clampf(ky * dxl, dyl, dyh)), e1 = q(dxh, gsr_clampf(ky * dxh, dyl, dyh));
-    const float e2 = q(gsr_clampf(kx * dyl, dxl, dxh), dyl), e3 = q(gsr_clampf(kx * dyh, dxl, dxh), dyh);
-    const bool inside = dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f;
-    const float qmax = inside ? 0.0f : fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
-    const float dxm = fmaxf(fabsf(dxl), fabsf(dxh)), dym = fmaxf(fabsf(dyl), fabsf(dyh));
-    const float mag = aA * dxm * dxm + aB * dxm * dym + aC * dym * dym;
-    if (qmax >= pmin - 2.0e-6f * mag) m |= 1u << s;
-  }
-  return m;
-}
-
 #ifndef BWD1_BATCH
 #define BWD1_BATCH 64
 #endif
@@ -921,14 +955,23 @@ void gsr_launch_render_fwd(const gsr_settings* s, int tiles, int grid_x, const u
                            const uint32_t* point_list, const float4* rec, float* out_color, float* out_invdepth,
                            float* final_T, uint32_t* n_contrib, const uint32_t* status_src, uint32_t* status_dst,
                            hipStream_t st) {
-  GSR_LAUNCH("render_fwd", k_render_fwd<false>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
-             ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr, status_src,
-             status_dst);
+  // GSR_FWD_MASK=1 selects the masked walk (measured: 0.208 against 0.179 ms at C3, profiles/r04_fwd_mask_ab.txt - not the default)
+  const char* mk = getenv("GSR_FWD_MASK");          // (read per call: the tests switch inside one process)
+  if (!(mk && !strcmp(mk, "1")))
+    GSR_LAUNCH("render_fwd", (k_render_fwd<false, false>), dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
+               ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr, status_src,
+               status_dst);
+  else
+    GSR_LAUNCH("render_fwd", (k_render_fwd<false, true>), dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
+               ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr, status_src,
+               status_dst);
 }
 
 void gsr_launch_count_pairs(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges, const uint32_t* point_list,
                             const float4* rec, uint32_t* pairs, hipStream_t st) {
-  hipLaunchKernelGGL(k_render_fwd<true>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x, ranges,
+  // (the instrumented build counts the entries the PUBLISHED loop evaluates per pixel - the unit of SURVEY 8(d)'s FLOP model -
+  // i.e. the unmasked walk; the masked production kernel evaluates fewer)
+  hipLaunchKernelGGL((k_render_fwd<true, false>), dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x, ranges,
                      point_list, rec, s->bg, (float*)nullptr, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, pairs,
                      (const uint32_t*)nullptr, (uint32_t*)nullptr);
 }

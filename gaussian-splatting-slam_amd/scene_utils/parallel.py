@@ -275,7 +275,9 @@ class ShardedStep:
     rank (identical inputs, identical results).  Element-wise optimizers only (Adam): a row's update does not depend on other
     rows, so the parameters equal those of the all-reduce schedule bit for bit."""
 
-    def __init__(self, model, make_optimizer, world: int, rank: int, group=None):
+    def __init__(self, model, make_optimizer, world: int, rank: int, group=None, init_from=None):
+        """init_from: an optimizer over the model's FULL parameters whose state (step, exp_avg, exp_avg_sq for every row) this
+        rank's shard starts from - how the moments come back after a densification re-shaped the model (`full_moments`)."""
         self.model, self.world, self.rank, self.group = model, world, rank, group
         P = int(model.get_xyz.shape[0])
         self.c = P // world
@@ -288,13 +290,52 @@ class ShardedStep:
             self.items.append((p, shard, rest))
             groups.append({"params": [shard] + ([rest] if rest is not None else []), "lr": g["lr"], "name": g["name"]})
         self.optimizer = make_optimizer(groups)
+        if init_from is not None:
+            for p, shard, rest in self.items:
+                st = init_from.state.get(p)
+                if not st or "exp_avg" not in st:
+                    continue
+                for part, rows in ((shard, slice(rank * self.c, (rank + 1) * self.c)), (rest, slice(self.P0, None))):
+                    if part is None or (part is shard and self.c == 0):
+                        continue
+                    self.optimizer.state[part] = {"step": st["step"].clone(), "exp_avg": st["exp_avg"][rows].clone(),
+                                                  "exp_avg_sq": st["exp_avg_sq"][rows].clone()}
 
     @torch.no_grad()
-    def step(self):
+    def full_moments(self):
+        """Per parameter (exp_avg, exp_avg_sq, step) for ALL rows - the ranks' shard moments all-gathered, the left-over rows'
+        (identical on every rank) appended - or None where no step has created them yet.  What a densification needs: its row
+        surgery (clone / split / prune) acts on whole tensors; ShardedStep(init_from=...) slices the result again."""
+        out = []
+        for p, shard, rest in self.items:
+            st = self.optimizer.state.get(shard) if self.c > 0 else (self.optimizer.state.get(rest) if rest is not None else None)
+            if not st or "exp_avg" not in st:
+                out.append(None)
+                continue
+            m, v = torch.empty_like(p.data), torch.empty_like(p.data)
+            if self.c > 0:
+                dist.all_gather_into_tensor(m[:self.P0], st["exp_avg"].contiguous(), group=self.group)
+                dist.all_gather_into_tensor(v[:self.P0], st["exp_avg_sq"].contiguous(), group=self.group)
+            if rest is not None:
+                sr = self.optimizer.state[rest]
+                m[self.P0:] = sr["exp_avg"]
+                v[self.P0:] = sr["exp_avg_sq"]
+            out.append((m, v, st["step"]))
+        return out
+
+    @torch.no_grad()
+    def step(self, skip=()):
+        """skip: parameters left alone this step - no exchange, no update (an opacity tensor that `reset_opacity` is about to
+        replace: the reference's optimizer skips it on that iteration because the new tensor carries no gradient)."""
         world, rank, c, P0 = self.world, self.rank, self.c, self.P0
         nccl = dist.get_backend(self.group) == "nccl"
         works, scaled = [], []
         for p, shard, rest in self.items:
+            if any(p is q for q in skip):
+                shard.grad = None
+                if rest is not None:
+                    rest.grad = None
+                continue
             g = p.grad if p.grad is not None else torch.zeros_like(p)
             g = g.contiguous()
             if c > 0:
@@ -324,6 +365,9 @@ class ShardedStep:
         self.optimizer.zero_grad(set_to_none=True)
         works = []
         for p, shard, rest in self.items:
+            if any(p is q for q in skip):
+                p.grad = None
+                continue
             if c > 0:
                 # (RCCL gathers in place when the input is the output's own slice; gloo gets a copy of the shard)
                 src = shard.data if nccl else shard.data.clone()

@@ -72,6 +72,7 @@ class Trainer:
             else:
                 from diff_gaussian_rasterization import FusedAdam
                 mk = lambda groups: FusedAdam(groups, lr=0.0, eps=1e-15)             # noqa: E731
+            self._mk_sharded = mk
             self.sharded = ShardedStep(model, mk, world, rank)
             self.optimizer = self.sharded.optimizer
         self.depth_targets, self.depth_weight = depth_targets, depth_weight
@@ -243,9 +244,18 @@ class Trainer:
             self._exchange_and_step_overlapped(vis.get() if self.optimizer_kind == "hip_sparse" else None, radii, rank1_cam)
             return self.last
         if self.sharded is not None:
-            if self.densify is not None:
-                raise NotImplementedError("exchange='sharded' with densification: the Adam moments live per row shard")
-            self.sharded.step()
+            # The same iteration the all-reduce schedule runs (reference order: train.py:155-168 densify / reset BETWEEN backward
+            # and optimizer.step, the replaced Parameters carry no gradient and are skipped by that step): a densification replaces
+            # every parameter - nothing is exchanged or applied; an opacity reset replaces `_opacity` alone - the other five step.
+            grow, reset = self._densify_plan()
+            if grow:
+                for p in self.model.parameters():
+                    p.grad = None
+            else:
+                self.sharded.step(skip=(self.model._opacity,) if reset else ())
+            if grow or reset:
+                with torch.no_grad():
+                    self._maybe_densify(radii)
             return self.last
         with torch.no_grad():
             if self.bucket is not None and rank1_cam is not None:
@@ -305,6 +315,13 @@ class Trainer:
             return False
         grow = it > d["from_iter"] and it % d["interval"] == 0 and not self._at_capacity()
         return grow or it % d["reset"] == 0
+
+    def _densify_plan(self, it=None):
+        """(densify_and_prune runs, reset_opacity runs) at iteration `it` (default: the current one) - what _maybe_densify does."""
+        d, it = self.densify, (self.iteration if it is None else it)
+        if d is None or it >= d["until_iter"]:
+            return False, False
+        return (it > d["from_iter"] and it % d["interval"] == 0 and not self._at_capacity()), it % d["reset"] == 0
 
     def _at_capacity(self):
         m = self.densify.get("max_gaussians") if self.densify else None
@@ -519,6 +536,14 @@ class Trainer:
         if it >= d["until_iter"]:
             return
         changed = False
+        grow, reset = self._densify_plan(it)
+        if self.sharded is not None and (grow or reset):
+            # exchange "sharded": the Adam moments exist per row shard.  The row surgery wants whole tensors: gather them (472 MB at
+            # 1 M Gaussians, once per densification interval), hand them to the model's own - in this mode otherwise stateless -
+            # optimizer, whose state densify_and_prune / reset_opacity carry through, and slice the result again below
+            for (p, _, _), m in zip(self.sharded.items, self.sharded.full_moments()):
+                if m is not None:
+                    self.model.optimizer.state[p] = {"step": m[2].clone(), "exp_avg": m[0], "exp_avg_sq": m[1]}
         if it > d["from_iter"] and it % d["interval"] == 0 and not self._at_capacity():
             # per-view statistics -> identical on all ranks, so every rank takes the same decisions
             reduce_densification_stats(self.model.xyz_gradient_accum, self.model.denom, self.model.max_radii2D, self.world,
@@ -530,6 +555,11 @@ class Trainer:
         if it % d["reset"] == 0:
             self.model.reset_opacity()
             changed = True
+        if changed and self.sharded is not None:
+            from .parallel import ShardedStep
+            self.sharded = ShardedStep(self.model, self._mk_sharded, self.world, self.rank, init_from=self.model.optimizer)
+            self.optimizer = self.sharded.optimizer
+            self.model.optimizer.state.clear()      # (the full-size moments were only passing through)
         if changed and self.bucket is not None:     # the replaced Parameters are new objects (and carry no gradient yet)
             self.bucket = GradBucket(self._arena_order_params())
         if changed and self.graph_replay:

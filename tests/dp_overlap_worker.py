@@ -15,7 +15,7 @@ from scene_utils import init_from_env, shard_views, Trainer, GaussianModel, make
 from gaussian_renderer import render, PipelineParams  # noqa: E402
 
 
-def run(overlap, optimizer, rank, world, steps=6, exchange="allreduce", fuse_rank1=True):
+def run(overlap, optimizer, rank, world, steps=6, exchange="allreduce", fuse_rank1=True, reset=50):
     dev = "cuda:0"
     raw = make_gaussians(3000, 2, seed=12, scale_factor=0.8)
     cams = fibonacci_cameras(4, 128, 80, seed=13, device=dev)
@@ -29,12 +29,14 @@ def run(overlap, optimizer, rank, world, steps=6, exchange="allreduce", fuse_ran
                  overlap_comm=overlap, exchange=exchange)
     assert tr.overlap_comm == overlap and tr.exchange == exchange
     tr.rank1_fuse_adam = fuse_rank1
-    tr.enable_densification(extent=4.4, from_iter=2, until_iter=100, interval=4, opacity_reset_interval=50, grad_threshold=2e-5)
+    tr.enable_densification(extent=4.4, from_iter=2, until_iter=100, interval=4, opacity_reset_interval=reset, grad_threshold=2e-5)
     mine = shard_views(len(cams), rank, world)
     for it in range(steps):
         tr.step(mine[it % len(mine)])
     tr.finish()
     torch.cuda.synchronize()
+    if exchange == "sharded":
+        assert tr.sharded is not None and tr.sharded.moment_bytes() < sum(p.numel() for p in model.parameters()) * 8 * 0.6
     return [p.detach().clone() for p in model.parameters()]
 
 
@@ -65,6 +67,19 @@ def main():
         other = b.clone()
         dist.broadcast(other, src=0)
         assert torch.equal(other, b), "ranks diverged (sh_rank1)"
+    # exchange="sharded" WITH densification (round 4): the moments live per row shard, a densification gathers them, carries them
+    # through the row surgery and slices them again; an opacity reset replaces one tensor.  9 steps: densifications at 4 and 8, a
+    # reset-only iteration at 5 (the opacity group is skipped by that step, the other five are applied) - the parameters must equal
+    # the all-reduce schedule's bit for bit (Adam is element-wise), on both ranks.
+    ref = run(False, "hip", rank, world, steps=9, reset=5)
+    sh = run(False, "hip", rank, world, steps=9, exchange="sharded", reset=5)
+    assert ref[0].shape[0] != 3000, "the scene did not densify"
+    for a, b in zip(ref, sh):
+        assert a.shape == b.shape and torch.equal(a, b), ("sharded + densification differs from the all-reduce schedule",
+                                                          float((a - b).abs().max()))
+        other = b.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(other, b), "ranks diverged (sharded + densification)"
     if rank == 0:
         print("DP_OVERLAP_OK")
     dist.barrier()

@@ -225,6 +225,38 @@ def test_backward_subblock_masks_change_no_bit(depth, aa, aniso):
         check_grads(b, ref)
 
 
+@pytest.mark.parametrize("aa,aniso,P,scale", [(False, 0.0, 6000, 0.8), (True, 1.3, 6000, 0.8), (False, 0.0, 20000, 2.5)])
+def test_forward_quadrant_masks_change_no_bit(aa, aniso, P, scale):
+    """Round 4, opt-in variant (GSR_FWD_MASK=1; measured slower than the plain loop, kept as evidence and exercised here): the
+    compositing forward walks, per 8x8 quadrant wave, only the list entries whose alpha >= 1/255 ellipse can reach that quadrant
+    (masks computed by the staging threads).  Entries it does walk take the published test in the published order, so
+    colour, inverse depth and - through final_T / n_contrib, which the backward replays - every gradient must equal the unmasked
+    loop's (GSR_FWD_MASK=0: the round-3 kernel) bit for bit; also on needles (anisotropic scales) and on a saturating scene (big
+    splats: most pixels finish early, the early-out and the masks interact)."""
+    raw = make_gaussians(P, 2, seed=411, scale_factor=scale)
+    if aniso:
+        gen = torch.Generator().manual_seed(412)
+        raw.scaling = raw.scaling + aniso * torch.randn(raw.scaling.shape, generator=gen)
+    cam = fibonacci_cameras(3, 208, 144, seed=413)[1]
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    gc, gd = upstream_grads(cam.image_height, cam.image_width)
+    old = os.environ.get("GSR_FWD_MASK")
+    try:
+        os.environ["GSR_FWD_MASK"] = "0"
+        a = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd)
+        os.environ["GSR_FWD_MASK"] = "1"
+        b = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd)
+    finally:
+        if old is None:
+            os.environ.pop("GSR_FWD_MASK", None)
+        else:
+            os.environ["GSR_FWD_MASK"] = old
+    assert torch.equal(a["color"], b["color"]) and torch.equal(a["invdepth"], b["invdepth"]) and torch.equal(a["radii"], b["radii"])
+    for k in a["grads"]:
+        assert torch.equal(a["grads"][k], b["grads"][k]), (k, float((a["grads"][k] - b["grads"][k]).abs().max()))
+    assert float(b["color"].sum()) > 0 and float(b["grads"]["means3D"].abs().sum()) > 0
+
+
 def test_bitwise_reproducible():
     """No float atomics anywhere: two runs give bit-identical images AND gradients (the reference's atomics do not)."""
     raw, cam = small_scene()
