@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
       const size_t b0 = (size_t)blockIdx.x * (256 * SUBTILES);
       for (uint32_t i = tid; i < (uint32_t)(256 * SUBTILES) && b0 + i < n0; i += 256) {
         const uint32_t kk = keys_in[b0 + i];
-        keys_out[b0 + i] = kk;
+        if (!RANGES) keys_out[b0 + i] = kk;
         vals_out[b0 + i] = vals_in ? vals_in[b0 + i] : (uint32_t)(b0 + i);
         if (DUAL) vals2_out[b0 + i] = vals2_in[b0 + i];
         if (RANGES) {      // (the array is sorted already: neighbours in memory are neighbours in the order)
@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
       const uint32_t kk = lbuf[i];
       const uint32_t d = (kk >> shift) & mask;
       gpos[k] = gbase[d] + (i - lstart[d]);
-      keys_out[gpos[k]] = kk;
+      // (RANGES = the tile sort's last pass: nobody reads the sorted tile ids - the ranges below are all that is wanted of them)
+      if (!RANGES) keys_out[gpos[k]] = kk;
       if (RANGES) {
         if (i == 0 || lbuf[i - 1] != kk) atomicMax(&ranges_enc[kk].x, ~gpos[k]);
         if (i + 1 == count || lbuf[i + 1] != kk) atomicMax(&ranges_enc[kk].y, gpos[k] + 1u);
