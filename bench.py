@@ -316,6 +316,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="N=1: the training step as ONE HIP graph launch (Trainer.enable_graph_replay: captured once per model "
                          "size, replayed; same results bit for bit).  Pays where the step is launch-bound (configs 1, 5)")
+    ap.add_argument("--cull", action="store_true",
+                    help="tile lists truncated by depth (Trainer.enable_tile_cull; implies --forward-mode async unless one is given): "
+                         "every view remembers the depth its tiles saturated at, its next render emits only what lies in front; a frame "
+                         "whose truncation was too tight is a no-op on the device and is run again - same parameters bit for bit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--forward-mode", default=None, choices=["exact", "async", "sync"],
@@ -387,6 +391,8 @@ def main():
     device = torch.device("cuda", local)
 
     import diff_gaussian_rasterization as dgr
+    if args.cull and not args.forward_mode:
+        args.forward_mode = "async"
     if args.forward_mode:
         dgr.set_forward_mode(args.forward_mode)
     model, cams, gts, depth_gts, my_views, pipe, bg, cfg, render, render_ground_truth = build_scene(args, device, rank, world)
@@ -396,6 +402,8 @@ def main():
                       overlap_comm=False if args.no_overlap else (True if args.overlap else None),
                       exchange=args.exchange, single_rank_group=single_rank_group)
     trainer.split_rows = bool(args.split_rows)
+    if args.cull:
+        trainer.enable_tile_cull()
     if args.graph:
         if world > 1 or single_rank_group:
             raise SystemExit("--graph: one rank only")
@@ -479,6 +487,8 @@ def main():
                          "async_frames": timed_stats["async_frames"], "sync_frames": timed_stats["sync_frames"],
                          "rerendered_frames": timed_stats["rerendered_frames"],
                          "overflow_frames": timed_stats["overflow_frames"], "rerun_views": trainer.rerun_views,
+                         "tile_cull": bool(args.cull), "culled_frames": timed_stats.get("culled_frames", 0),
+                         "cull_miss_frames": timed_stats.get("cull_miss_frames", 0),
                          "tile_local_frames": timed_stats.get("tile_local_frames", 0),
                          "tile_local_frames_timed": timed_stats.get("tile_local_frames", 0)
                                                     - stats_before.get("tile_local_frames", 0)},

@@ -11,10 +11,13 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+
 #include "gsr_common.h"
 
 // launchers defined in the kernel files
-void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool, bool, uint32_t*, int, hipStream_t);
+void gsr_launch_preprocess_fwd(const gsr_settings*, const gsr_gaussians*, int32_t*, char*, const GsrGeomLayout&, bool, bool, uint32_t*, int,
+                               const uint32_t*, uint32_t*, uint32_t, hipStream_t);
 void gsr_launch_shade(const gsr_settings*, const gsr_gaussians*, char*, const GsrGeomLayout&, bool, hipStream_t);
 void gsr_launch_adam_culled_rows(int, int, const char*, const GsrGeomLayout&, const GsrAdamArgs&, uint32_t, hipStream_t);
 int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const int32_t*, const char*,
@@ -22,13 +25,14 @@ int gsr_launch_preprocess_bwd(const gsr_settings*, const gsr_gaussians*, const i
                               hipStream_t);
 void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStream_t);
 void gsr_launch_emit(int, int, int, char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, bool, unsigned long long*,
-                     int, hipStream_t);
+                     int, const uint32_t*, hipStream_t);
 void gsr_launch_tile_depth_sort(int, bool, uint2*, const uint2*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*,
                                 uint32_t*, uint32_t*, hipStream_t);
 void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
-                           float*, float*, uint32_t*, const uint32_t*, uint32_t*, hipStream_t);
+                           float*, float*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,
+                           uint32_t, uint32_t*, hipStream_t);
 void gsr_launch_count_pairs(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, uint32_t*,
                             hipStream_t);
 void gsr_launch_render_bwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*,
@@ -293,7 +297,9 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
                             hipEvent_t copied /* recorded right behind the status copy, or nullptr */,
                             SideShade* shade_aside = nullptr, bool tile_local = false,
                             unsigned long long** early_word = nullptr,
-                            uint32_t* tile_sort_head = nullptr /* tile-local form: cleared by the projection kernel */) {
+                            uint32_t* tile_sort_head = nullptr /* tile-local form: cleared by the projection kernel */,
+                            const uint32_t* tile_cutoff = nullptr /* lists truncated by depth (gsr_forward_async_culled) */,
+                            uint32_t* culled_any = nullptr, uint32_t frame_tag = 0) {
   const int P = g->P;
   const GsrGeomLayout L = gsr_geom_layout(P);
   if (!geometry_state || geometry_bytes < L.total) {
@@ -310,7 +316,7 @@ static int forward_geometry(const gsr_settings* s, const gsr_gaussians* g, void*
   if (!tile_local && (rc = gsr_check(hipMemsetAsync(meta, 0, 256 + GSR_RADIX_HEAD_WORDS * 4, st), "memset meta"))) return rc;
 
   gsr_launch_preprocess_fwd(s, g, radii, geom, L, defer_color, /*block_sums=*/tile_local, tile_local ? tile_sort_head : nullptr,
-                            GSR_RADIX_HEAD_WORDS, st);
+                            GSR_RADIX_HEAD_WORDS, tile_cutoff, culled_any, frame_tag, st);
   if ((rc = debug_sync(s, st, "preprocess"))) return rc;
   // (tile-local binning form: the colour pass is forked behind the emission instead - forward_render_impl - because the
   // two are both HBM-bound and slowed each other down (emission 36 -> 55 us); the tile sort and the per-tile ordering that
@@ -463,7 +469,10 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
                                hipEvent_t sh_ready, void* stream, bool tile_local = false,
                                uint32_t* host_status_late = nullptr, unsigned long long* early = nullptr,
                                uint32_t* host_count = nullptr, hipEvent_t count_copied = nullptr,
-                               bool sort_head_clean = false /* this call's projection kernel cleared the tile sort's head */) {
+                               bool sort_head_clean = false /* this call's projection kernel cleared the tile sort's head */,
+                               uint32_t* tile_cutoff = nullptr /* per-tile depth cut-off: updated by the compositing kernel */,
+                               bool cull_applied = false /* ... and the projection counted with it: emit with it too */,
+                               uint32_t frame_tag = 0) {
   int rc = validate(s, g);
   if (rc) return rc;
   if (num_rendered < 0 || num_rendered > 0x3FFFFFFFll) {   // the tile sort counts keys in 30-bit fields (sort_scan.hip)
@@ -499,7 +508,8 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
     if (fused_bins && !sort_head_clean &&
         (rc = gsr_check(hipMemsetAsync(bin + BL.radix_tmp, 0, GSR_RADIX_HEAD_WORDS * 4, st), "memset sort head")))
       return rc;
-    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, early, fused_bins ? tile_bits(tiles) : 0, st);
+    gsr_launch_emit(g->P, gx, tiles, geom, GL, bin, BL, (uint32_t)R, tile_local, early, fused_bins ? tile_bits(tiles) : 0,
+                    cull_applied ? tile_cutoff : nullptr, st);
     // tile-local form: the emission kernel is where num_rendered comes into being.  A waiting caller whose pinned slot has no
     // device alias (early == nullptr) gets the status words by a copy, marked by an event
     if (tile_local && host_count && !early) {
@@ -572,7 +582,8 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   gsr_launch_render_fwd(s, tiles, gx, (const uint2*)(bin + BL.ranges), (const uint32_t*)(bin + point_list_offset(BL, tiles)),
                         (const float4*)(geom + GL.rec), out_color, out_invdepth, (float*)(img + IL.final_T),
                         (uint32_t*)(img + IL.n_contrib), status_dev ? (const uint32_t*)(geom + GL.meta) : nullptr, status_dev,
-                        st);
+                        (g->P > 0 && R > 0) ? tile_cutoff : nullptr, (const uint32_t*)(geom + GL.depth_key),
+                        cull_applied ? (const uint32_t*)(bin + BL.culled_any) : nullptr, frame_tag, (uint32_t*)(geom + GL.meta), st);
   if ((rc = debug_sync(s, st, "render forward"))) return rc;
   return gsr_launch_status("forward");
 }
@@ -592,11 +603,11 @@ int gsr_forward_render_shade(const gsr_settings* s, const gsr_gaussians* g, void
                              out_color, out_invdepth, for_backward != 0, true, (hipEvent_t)sh_ready_event, stream);
 }
 
-int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
+static int forward_async_impl(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
                       int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
                       size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
                       int32_t defer_color, void* sh_ready_event, uint32_t* host_status, int32_t tile_local_sort,
-                      void* stream, int64_t* num_rendered_out) {
+                      void* stream, int64_t* num_rendered_out, uint32_t* tile_cutoff, bool cull_apply) {
   int rc = validate(s, g);
   if (rc) return rc;
   const bool tlo = tile_local_sort != 0;
@@ -621,19 +632,31 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
     // (tile-local form: the projection kernel clears the head of the tile sort's scratch in the caller's binning state, so that
     // the emission's workgroups can add their digit counts to it)
     uint32_t* sort_head = nullptr;
+    uint32_t* culled_any = nullptr;
+    static std::atomic<uint32_t> frame_counter{0};
+    const uint32_t frame_tag = ++frame_counter | 0x40000000u;     // (never 0: what a cleared buffer holds)
+    // lists truncated by the per-tile depth cut-off: only on the path whose frames are looked at AFTERWARDS (unverified: a frame
+    // whose truncation turns out too tight flags itself, its backward is a no-op, the caller renders it again), in the tile-local
+    // binning form (the projection kernel clears the per-tile "lost an instance" flags next to the sort's head)
+    bool cull = cull_apply && tile_cutoff != nullptr && tlo && num_rendered_out == nullptr && !s->debug;
     if (tlo && binning_state && capacity > 0) {
       const int gx0 = (s->image_width + GSR_TILE - 1) / GSR_TILE, gy0 = (s->image_height + GSR_TILE - 1) / GSR_TILE;
       const GsrBinLayout BL0 = gsr_bin_layout((size_t)capacity, (size_t)gx0 * gy0);
-      if (binning_bytes >= BL0.total) sort_head = (uint32_t*)((char*)binning_state + BL0.radix_tmp);
+      if (binning_bytes >= BL0.total) {
+        sort_head = (uint32_t*)((char*)binning_state + BL0.radix_tmp);
+        culled_any = (uint32_t*)((char*)binning_state + BL0.culled_any);
+      }
     }
+    if (!culled_any) cull = false;
     if ((rc = forward_geometry(s, g, geometry_state, geometry_bytes, radii, (hipStream_t)stream, late || aside != nullptr,
-                               host, ev, aside, tlo, &early, sort_head)))
+                               host, ev, aside, tlo, &early, sort_head, cull ? tile_cutoff : nullptr, cull ? culled_any : nullptr,
+                               frame_tag)))
       return rc;
     // (the caller's status words - flags, num_rendered and, in the tile-local form, the longest tile list meta[4] - leave at the END)
     rc = forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, capacity, image_state, image_bytes,
                              out_color, out_invdepth, for_backward != 0, aside ? false : late,
                              aside ? aside->join : (hipEvent_t)sh_ready_event, stream, tlo, host_status, early, tlo ? host : nullptr,
-                             ev, /*sort_head_clean=*/sort_head != nullptr);
+                             ev, /*sort_head_clean=*/sort_head != nullptr, tile_cutoff, cull, frame_tag);
     if (rc) return rc;
     if (num_rendered_out) {
       const int64_t n = wait_for_count(host, ev, early != nullptr);
@@ -644,6 +667,26 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
   }
   return forward_render_impl(s, g, geometry_state, binning_state, binning_bytes, 0, image_state, image_bytes, out_color,
                              out_invdepth, for_backward != 0, false, nullptr, stream);
+}
+
+int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
+                      int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
+                      size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
+                      int32_t defer_color, void* sh_ready_event, uint32_t* host_status, int32_t tile_local_sort,
+                      void* stream, int64_t* num_rendered_out) {
+  return forward_async_impl(s, g, geometry_state, geometry_bytes, radii, binning_state, binning_bytes, capacity, image_state,
+                            image_bytes, out_color, out_invdepth, for_backward, defer_color, sh_ready_event, host_status,
+                            tile_local_sort, stream, num_rendered_out, nullptr, false);
+}
+
+int gsr_forward_async_culled(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
+                             int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
+                             size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
+                             int32_t defer_color, void* sh_ready_event, uint32_t* host_status, int32_t tile_local_sort,
+                             void* stream, int64_t* num_rendered_out, uint32_t* tile_depth_cutoff, int32_t apply) {
+  return forward_async_impl(s, g, geometry_state, geometry_bytes, radii, binning_state, binning_bytes, capacity, image_state,
+                            image_bytes, out_color, out_invdepth, for_backward, defer_color, sh_ready_event, host_status,
+                            tile_local_sort, stream, num_rendered_out, tile_depth_cutoff, apply != 0);
 }
 
 int gsr_forward_rerender(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, void* binning_state,

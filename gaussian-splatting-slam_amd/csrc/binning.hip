@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
                                                         uint2* __restrict__ ranges, uint32_t cap,
                                                         uint32_t* __restrict__ sort_head, uint32_t* __restrict__ meta,
                                                         unsigned long long* __restrict__ early, int hist_bits,
-                                                        size_t lookback_words) {
+                                                        size_t lookback_words,
+                                                        const uint32_t* __restrict__ tile_cutoff /* nullptr: emit everything */,
+                                                        const uint32_t* __restrict__ depth_key) {
   __shared__ uint32_t lkey[EMIT_WINDOW], lgid[EMIT_WINDOW];
   __shared__ uint32_t wave_tot[4];
   __shared__ unsigned long long wave_pre[4];
@@ -139,12 +141,35 @@ __global__ __launch_bounds__(256) void k_emit_instances(int P, int grid_x, const
       const ushort4 r = make_ushort4((unsigned short)(rlo & 0xFFFFu), (unsigned short)(rlo >> 16),
                                      (unsigned short)(rhi & 0xFFFFu), (unsigned short)(rhi >> 16));
       const uint32_t end = off + n;
+      const uint32_t zbits = tile_cutoff ? depth_key[g] : 0u;   // (truncation by depth: the comparison k_preprocess_fwd counted with)
       uint32_t* kdst = staged ? lkey : tile_key;
       uint32_t* gdst = staged ? lgid : gauss_of_slot;
       const uint32_t bias = staged ? slot0 : 0u;
       for (int y = r.y; y < r.w; y++) {
         const uint32_t iv = gsr_row_interval(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, y, r.x, r.z);
         const int lo = (int)(iv & 0xFFFFu), hi = (int)(iv >> 16);
+        if (tile_cutoff) {
+          // lists truncated by depth: behind a tile's cut-off an instance is not emitted (nor was it counted); four cut-offs in
+          // flight per trip
+          const uint32_t* crow = tile_cutoff + y * grid_x;
+          for (int x = lo; x < hi && off < end; x += 4) {
+            uint32_t c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) c[u] = x + u < hi ? crow[x + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              if (x + u < hi && zbits <= c[u] && off < end) {
+                if (staged || off < cap) {
+                  kdst[off - bias] = (uint32_t)(y * grid_x + x + u);
+                  gdst[off - bias] = g;
+                  if (hist_bits > 0 && !staged) count_digits((uint32_t)(y * grid_x + x + u));
+                }
+                off++;
+              }
+            }
+          }
+          continue;
+        }
         for (int x = lo; x < hi && off < end; x++) {
           if (staged || off < cap) {   // (direct path) slots beyond the binning state's capacity are dropped, see below
             kdst[off - bias] = (uint32_t)(y * grid_x + x);
@@ -443,7 +468,7 @@ void gsr_launch_tile_depth_sort(int tiles, bool dual, uint2* ranges, const uint2
 // digit histograms and clears its look-back table; the encoded tile ranges (BL.ranges_enc) are what it zero-initialises then
 void gsr_launch_emit(int P, int grid_x, int tiles, char* geom, const GsrGeomLayout& GL, char* bin,
                      const GsrBinLayout& BL, uint32_t cap, bool index_order, unsigned long long* early, int count_hist_bits,
-                     hipStream_t st) {
+                     const uint32_t* tile_cutoff, hipStream_t st) {
   // (the look-back words of the sort's FIRST pass; every pass clears the next one's itself - sort_scan.hip)
   const size_t lb_words = count_hist_bits > 0 ? (size_t)gsr_radix_blocks(cap) * GSR_RADIX_SIZE : 0;
   GSR_LAUNCH("emit_instances", k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, st, P, grid_x,
@@ -452,7 +477,8 @@ void gsr_launch_emit(int P, int grid_x, int tiles, char* geom, const GsrGeomLayo
              (const float4*)(geom + GL.bin_rec), (uint32_t*)(bin + BL.key_a), (uint32_t*)(bin + BL.gauss_of_slot),
              (uint32_t*)(geom + GL.slot_start), tiles, (uint2*)(bin + (count_hist_bits > 0 ? BL.ranges_enc : BL.ranges)), cap,
              (uint32_t*)(bin + BL.radix_tmp), (uint32_t*)(geom + GL.meta),
-             index_order ? early : (unsigned long long*)nullptr, count_hist_bits, lb_words);
+             index_order ? early : (unsigned long long*)nullptr, count_hist_bits, lb_words, tile_cutoff,
+             (const uint32_t*)(geom + GL.depth_key));
 }
 
 void gsr_launch_finalize(uint32_t cap, const uint32_t* n_dev, const uint32_t* tile_sorted, char* bin,

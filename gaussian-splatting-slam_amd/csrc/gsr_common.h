@@ -53,6 +53,8 @@ struct GsrBinLayout {
   size_t gauss_of_slot;  // u32[R] Gaussian id of each emission slot; second payload of the tile sort, ping-pongs with
   size_t point_list;     // u32[R] -> Gaussian ids sorted by (tile, depth, id) end up in ONE of the two (pass parity)
   size_t ranges;         // uint2[tiles]
+  size_t culled_any;     // u32[tiles]: == the frame's tag where tile t lost an instance to its depth cut-off (gsr_forward_async_culled;
+  //                        a tag per frame instead of a flag: nothing has to be cleared before the projection kernel sets it)
   size_t ranges_enc;     // uint2[tiles]: (~first position, last position + 1) by atomicMax from the tile sort's last pass
   //                        (tile-local binning form), decoded into `ranges` by k_tile_depth_sort
   size_t scan_tmp;
@@ -158,6 +160,7 @@ static inline GsrBinLayout gsr_bin_layout(size_t R, size_t tiles) {
   L.point_list = o;    o += gsr_align(R * 4);
   L.ranges = o;        o += gsr_align(tiles * 8);
   L.ranges_enc = o;    o += gsr_align(tiles * 8);
+  L.culled_any = o;    o += gsr_align(tiles * 4);
   L.scan_tmp = o;      o += gsr_align(gsr_scan_tmp_elems(R) * 4);
   L.radix_tmp = o;     o += gsr_align(gsr_radix_tmp_elems(R) * 4);
   L.total = o;
@@ -243,6 +246,11 @@ int gsr_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
 // times out (a broken hand-off protocol: the pass then goes on with a WRONG base, the grid drains, the frame is mis-sorted) ORs
 // GSR_STATUS_SORT_TIMEOUT into it, so the failure reaches the caller instead of staying a mark in device memory.
 #define GSR_STATUS_SORT_TIMEOUT 1u
+// (round 4) tile-list truncation by a per-tile depth cut-off (gsr_forward_async_culled): a pixel that reached the END of a truncated
+// list without saturating might have blended a culled Gaussian - the frame is not the frame.  The compositing kernel raises this
+// bit in meta[0] (every backward kernel then turns the step into a no-op, like a frame beyond the capacity: gsr_overflowed) and
+// stores 1 into word 6 of the caller's status slot.
+#define GSR_STATUS_CULL_MISS 2u
 // head_zeroed: the caller guarantees that the first GSR_RADIX_HEAD_WORDS words of `tmp` are zero when the sort's first kernel
 // starts (an earlier kernel of the same stream cleared them); otherwise the sort enqueues a memset of its own.
 
@@ -265,7 +273,9 @@ __device__ __forceinline__ uint32_t gsr_eff_n(const uint32_t* __restrict__ n_dev
 // list: its image is not the frame's image, so nothing may be learnt from it.  Every backward kernel tests this (one scalar
 // load) and turns the whole step into a no-op: no gradient records, zero gradients, no optimizer update, no statistics.
 __device__ __forceinline__ bool gsr_overflowed(const uint32_t* __restrict__ n_dev, uint32_t cap) {
-  return n_dev != nullptr && (n_dev[1] != 0u || n_dev[0] > cap);
+  // (n_dev = meta + 2 wherever it is not null: meta[0] holds the frame's status flags - a list truncated by the depth cut-off
+  // that turned out to be too short makes the frame as unusable as one beyond the capacity)
+  return n_dev != nullptr && (n_dev[1] != 0u || n_dev[0] > cap || (*(n_dev - 2) & GSR_STATUS_CULL_MISS) != 0u);
 }
 
 // One Adam update, shared by k_adam (adam.hip) and the step folded into k_preprocess_bwd (preprocess.hip): every rounding is

@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     uint32_t* __restrict__ order, uint32_t* __restrict__ tiles_touched, ushort4* __restrict__ rect,
     float4* __restrict__ bin_rec,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ meta, uint32_t* __restrict__ block_sums,
-    uint32_t* __restrict__ zero_words, int n_zero_words) {
+    uint32_t* __restrict__ zero_words, int n_zero_words,
+    const uint32_t* __restrict__ tile_cutoff /* nullptr, or per tile the depth bits beyond which nothing is emitted */,
+    uint32_t* __restrict__ culled_any /* [tiles]: set to frame_tag where an instance is dropped */, uint32_t frame_tag) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
   // (round 4) the head of the tile sort's scratch - histogram replicas + pass tickets - is cleared HERE, one kernel ahead of
   // k_emit_instances, whose workgroups all add their digit counts to it (binning.hip)
@@ -370,9 +372,30 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
           sA = (-0.5f * GSR_LOG2E) * cA; sB = -GSR_LOG2E * cB; sC = (-0.5f * GSR_LOG2E) * cC;
           spmin = GSR_LOG2E * pmin;
           int kept = 0;
+          const uint32_t zbits = __float_as_uint(t[2]);
           for (int ty = cy0; ty < cy1; ty++) {
             const uint32_t iv = gsr_row_interval(px, py, sA, sB, sC, spmin, ty, cx0, cx1);
-            kept += (int)(iv >> 16) - (int)(iv & 0xFFFFu);
+            if (tile_cutoff) {
+              // (round 4) lists truncated by depth: a tile whose every pixel saturated in front of `tile_cutoff[tile]` when this view
+              // was last rendered takes no instance behind it - the emission applies the very same comparison
+              // (four cut-offs in flight per trip: one dependent L2 round trip per tile made this loop +12 us at C3, +53 us on big splats)
+              const int lo = (int)(iv & 0xFFFFu), hi = (int)(iv >> 16);
+              const uint32_t* crow = tile_cutoff + ty * gx;
+              for (int tx = lo; tx < hi; tx += 4) {
+                uint32_t c[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) c[u] = tx + u < hi ? crow[tx + u] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  if (tx + u < hi) {
+                    if (zbits <= c[u]) kept++;
+                    else culled_any[ty * gx + tx + u] = frame_tag;   // the tile's list is not whole in this frame (same-value races are fine)
+                  }
+                }
+              }
+            } else {
+              kept += (int)(iv >> 16) - (int)(iv & 0xFFFFu);
+            }
           }
           if (kept == 0) { cx0 = cx1 = cy0 = cy1 = 0; }
           out_radius = (int32_t)radius;        // radii / visibility are the published ones (3-sigma rectangle non-empty)
@@ -1211,7 +1234,8 @@ void gsr_launch_shade(const gsr_settings* s, const gsr_gaussians* g, char* geom,
 // array: [0, nb) totals, [nb, 2 nb) start slots, nb = ceil(P / 256)
 void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, int32_t* radii, char* geom,
                                const GsrGeomLayout& L, bool defer_color, bool block_sums, uint32_t* zero_words,
-                               int n_zero_words, hipStream_t st) {
+                               int n_zero_words, const uint32_t* tile_cutoff, uint32_t* culled_any, uint32_t frame_tag,
+                               hipStream_t st) {
   const int P = g->P;
   size_t lds = 0;
   const bool stage = !defer_color && can_stage_sh(s, g, &lds);
@@ -1222,7 +1246,8 @@ void gsr_launch_preprocess_fwd(const gsr_settings* s, const gsr_gaussians* g, in
       (float4*)(geom + L.rec),                                                                                       \
       (uint32_t*)(geom + L.depth_key), (uint32_t*)(geom + L.order), (uint32_t*)(geom + L.tiles_touched),              \
       (ushort4*)(geom + L.rect), (float4*)(geom + L.bin_rec), (uint8_t*)(geom + L.clamped), (uint32_t*)(geom + L.meta), \
-      block_sums ? (uint32_t*)(geom + L.offsets) : (uint32_t*)nullptr, zero_words, n_zero_words
+      block_sums ? (uint32_t*)(geom + L.offsets) : (uint32_t*)nullptr, zero_words, n_zero_words, tile_cutoff,       \
+      culled_any, frame_tag
   if (stage)
     GSR_LAUNCH("preprocess_fwd", k_preprocess_fwd<true>, dim3((P + 255) / 256), dim3(256), lds, st, GSR_PRE_FWD_ARGS);
   else

@@ -272,8 +272,14 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
                                                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                     uint32_t* __restrict__ pairs,
                                                     const uint32_t* __restrict__ status_src,
-                                                    uint32_t* __restrict__ status_dst) {
+                                                    uint32_t* __restrict__ status_dst,
+                                                    uint32_t* __restrict__ tile_cutoff /* in/out, or nullptr */,
+                                                    const uint32_t* __restrict__ depth_key,
+                                                    const uint32_t* __restrict__ culled_any /* nullptr: lists not truncated */,
+                                                    uint32_t frame_tag, uint32_t* __restrict__ meta, uint32_t margin_q8,
+                                                    uint32_t margin_add) {
   __shared__ float4 s0[FWD_BATCH + 6], s1[FWD_BATCH + 6], s2[FWD_BATCH];  // +6: the prefetch may touch [n+5]
+  __shared__ uint32_t s_need;
   __shared__ uint32_t smask[MASKED ? FWD_BATCH : 1];                      // (MASKED) reachable quadrants of every staged entry
   const int tile = blockIdx.x;
   // non-blocking forward: the frame's status words (flags, num_rendered, longest tile list - final since the previous
@@ -282,7 +288,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   // system-scope fence, so a host that sees it overwritten also sees flags and num_rendered of THIS frame (not a replay's
   // predecessor's).
   if (status_dst && blockIdx.x == 0 && threadIdx.x < 8) {
-    if (threadIdx.x != 4) status_dst[threadIdx.x] = status_src[threadIdx.x];
+    // (word 6 is not copied: it is the host's to clear and any workgroup's to set - "a truncated tile list was too short")
+    if (threadIdx.x != 4 && threadIdx.x != 6) status_dst[threadIdx.x] = status_src[threadIdx.x];
     __threadfence_system();
     if (threadIdx.x == 4) status_dst[4] = status_src[4];
   }
@@ -303,6 +310,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
   uint64_t live = BALLOT(inside);
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   uint32_t last = 0, visited = 0, blended = 0;
+  uint32_t stop_at = 0;     // 1-based list position of the entry this pixel saturated at (0: it has not)
+  if (tile_cutoff && threadIdx.x == 0) s_need = 0u;
   int vzero;   // keeps the LDS base in a VGPR (see k_render_bwd)
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   const float4 *s0v = s0 + vzero, *s1v = s1 + vzero, *s2v = s2 + vzero;
@@ -350,6 +359,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
         D += c.z * wgt;
         T = blend ? test_T : T;
         last = blend ? (uint32_t)(r * FWD_BATCH + j + 1) : last;
+        stop_at = stop ? (uint32_t)(r * FWD_BATCH + j + 1) : stop_at;
         pxe = stop ? 1.0e15f : pxe;
         // (ballots taken straight off the three compares: the AND happens on the scalar unit)
         live &= ~(BALLOT(power <= 0.0f) & BALLOT(alpha >= ALPHA_MIN) & BALLOT(test_T < 0.0001f));  // quadrant saturated -> leave
@@ -398,6 +408,39 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
       pairs[(size_t)W * H + (size_t)py * W + px] = blended;
     }
     return;
+  }
+  if (tile_cutoff) {
+    // (round 4) How much of this tile's list the frame NEEDED: the deepest entry any of its pixels saturated at - or all of it
+    // and more, if a pixel never saturated.  Its depth, with a margin (1.75 x as many entries + 48), is the tile's cut-off for
+    // the next render of this view (gsr_forward_async_culled): instances behind it are not even emitted then.  And if THIS
+    // frame's list was truncated (culled_any) and a pixel ran off its end unsaturated, a culled Gaussian might have been
+    // blended: the frame is flagged, every backward kernel skips it (gsr_overflowed), the caller renders it again untruncated.
+    uint32_t need = inside ? (stop_at != 0u ? stop_at : 0xFFFFFFFFu) : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) need = max(need, (uint32_t)__shfl_xor((int)need, d, 64));
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_need, need);
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t nd = s_need, len = range.y - range.x;
+      const bool truncated = culled_any != nullptr && culled_any[tile] == frame_tag;
+      if (nd == 0xFFFFFFFFu) {
+        if (truncated) {
+          atomicOr(&meta[0], GSR_STATUS_CULL_MISS);
+          if (status_dst) status_dst[6] = 1u;
+        }
+        tile_cutoff[tile] = 0xFFFFFFFFu;
+      } else {
+        // margin: need x margin_q8 / 256 + margin_add entries (GSR_CULL_MARGIN="q8,add" overrides the launcher's default)
+        const uint32_t k = (uint32_t)(((unsigned long long)nd * margin_q8) >> 8) + margin_add;   // (positions are 1-based: index k is entry k + 1)
+        if (k < len) {
+          const uint32_t id = point_list[range.x + k];
+          tile_cutoff[tile] = id != 0xFFFFFFFFu ? depth_key[id] : 0xFFFFFFFFu;
+        } else if (!truncated) {
+          tile_cutoff[tile] = 0xFFFFFFFFu;                  // the margin reaches past the whole list: nothing to cut
+        }                                                   // (else: keep the wider cut-off this frame was rendered with)
+      }
+    }
   }
   if (inside) {
     const size_t pix = (size_t)py * W + px;
@@ -954,17 +997,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
 void gsr_launch_render_fwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,
                            const uint32_t* point_list, const float4* rec, float* out_color, float* out_invdepth,
                            float* final_T, uint32_t* n_contrib, const uint32_t* status_src, uint32_t* status_dst,
-                           hipStream_t st) {
+                           uint32_t* tile_cutoff, const uint32_t* depth_key, const uint32_t* culled_any, uint32_t frame_tag,
+                           uint32_t* meta, hipStream_t st) {
+  // cut-off margin of the depth-truncated lists: 1.75 x the entries a tile needed + 48 (measured, profiles/r04_tile_cull.txt: 1.25 x + 16
+  // flags 54 % of the frames of a run that trains from scratch, 1.5 x + 32 1 %, 1.75 x + 48 none; C3 and the 2 x splats scene)
+  unsigned mq8 = 448, madd = 48;
+  if (const char* mg = getenv("GSR_CULL_MARGIN")) sscanf(mg, "%u,%u", &mq8, &madd);
   // GSR_FWD_MASK=1 selects the masked walk (measured: 0.208 against 0.179 ms at C3, profiles/r04_fwd_mask_ab.txt - not the default)
   const char* mk = getenv("GSR_FWD_MASK");          // (read per call: the tests switch inside one process)
   if (!(mk && !strcmp(mk, "1")))
     GSR_LAUNCH("render_fwd", (k_render_fwd<false, false>), dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
                ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr, status_src,
-               status_dst);
+               status_dst, tile_cutoff, depth_key, culled_any, frame_tag, meta, mq8, madd);
   else
     GSR_LAUNCH("render_fwd", (k_render_fwd<false, true>), dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
                ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr, status_src,
-               status_dst);
+               status_dst, tile_cutoff, depth_key, culled_any, frame_tag, meta, mq8, madd);
 }
 
 void gsr_launch_count_pairs(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges, const uint32_t* point_list,
@@ -973,7 +1021,8 @@ void gsr_launch_count_pairs(const gsr_settings* s, int tiles, int grid_x, const 
   // i.e. the unmasked walk; the masked production kernel evaluates fewer)
   hipLaunchKernelGGL((k_render_fwd<true, false>), dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x, ranges,
                      point_list, rec, s->bg, (float*)nullptr, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, pairs,
-                     (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                     (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                     (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, 0u, 0u);
 }
 
 void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,

@@ -77,6 +77,10 @@ EXPORTS = {
                                     C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                     C.POINTER(C.c_int64)]),
+    "gsr_forward_async_culled": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                    C.POINTER(C.c_int64), C.c_void_p, C.c_int32]),
     "gsr_forward_rerender": (C.c_int, [C.POINTER(gsr_settings), C.POINTER(gsr_gaussians), C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p]),

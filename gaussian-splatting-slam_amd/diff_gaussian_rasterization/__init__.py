@@ -198,6 +198,16 @@ def graph_status_slot(device=None):
     return getattr(_ws.pool(dev), "graph_status", None)
 
 
+def new_tile_cull(image_height, image_width, device="cuda"):
+    """Per-tile depth cut-offs of ONE view, for `GaussianRasterizer.forward(..., tile_cull=...)`: int32[tiles], all bits set = no
+    limit.  Keep one per camera that is rendered again and again (the cameras of a training set): every speculative forward of the
+    view updates it, every UNVERIFIED forward (mode "async") of the view emits only the instances in front of it.  A frame whose
+    truncation turns out too tight flags itself (its backward is a no-op, its ticket is reported by `take_overflowed`) and the
+    caller renders it again - scene_utils.Trainer does."""
+    tiles = ((int(image_width) + 15) // 16) * ((int(image_height) + 15) // 16)
+    return torch.full((tiles,), -1, dtype=torch.int32, device=device)
+
+
 def last_ticket(device=None):
     """Ticket of the most recent speculative forward on this device (1, 2, ...): what `take_overflowed` reports."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -273,12 +283,14 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                raster_settings, raw_activations=False, for_backward=True, fold=None, sh_ready_event=None, forward_mode=None):
+                raster_settings, raw_activations=False, for_backward=True, fold=None, sh_ready_event=None, forward_mode=None,
+                tile_cull=None, tile_cull_apply=True):
         """fold: a BackwardFold for THIS call's backward (kept on ctx).  sh_ready_event: a recorded torch.cuda.Event after which
         `dc` / `shs` hold this step's values (the view-sharded trainer's SH all-reduce + Adam update, in flight on another
         stream): the geometry stages run first, the stream waits for the event and only then evaluates the colours
         (gsr_forward_prepare_geometry / gsr_forward_shade).  forward_mode: "exact" | "async" | "sync" for this call (default:
-        the process-wide mode, GSR_FORWARD_MODE / set_forward_mode)."""
+        the process-wide mode, GSR_FORWARD_MODE / set_forward_mode).  tile_cull: this VIEW's per-tile depth cut-offs
+        (`new_tile_cull`), updated by every speculative forward and applied by unverified ones (gsr_forward_async_culled)."""
         lib = _C.lib()
         raw_activations = bool(raw_activations) and cov3D_precomp is None
         if not means3D.is_cuda:
@@ -342,16 +354,28 @@ class _RasterizeGaussians(torch.autograd.Function):
                     binning = ws.ensure_binning(lib, P, W, H, R)
                     status = pool.status_slot()
                     status[2] = _ws.STATUS_PENDING     # (overwritten by the compositing kernel when the frame's status arrives)
+                    status[3] = 0                      # (word 6: set by the compositing kernel if a truncated tile list was too short)
                     tlo = 1 if _ws.tile_local_binning(pool, key) else 0
                     count = C.c_int64(-1)
                     rerendered = False
                     verify = mode == "exact" or key not in pool.capacity     # ("async": a shape's first frame is verified too -
                     #                                                           its capacity is a guess, not an observation)
-                    _C.check(lib.gsr_forward_async(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
-                                                   _C.ptr(binning), binning.numel(), R, _C.ptr(img), img.numel(),
-                                                   _C.ptr(color), _C.ptr(invdepth), 1 if needs_grad else 0,
-                                                   1 if split else 0, evh, C.c_void_p(status.data_ptr()), tlo, stream,
-                                                   C.byref(count) if verify else None))
+                    if tile_cull is not None:
+                        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+                        if tile_cull.dtype != torch.int32 or tile_cull.numel() != tiles or tile_cull.device != dev \
+                                or not tile_cull.is_contiguous():
+                            raise _C.GsrError(f"tile_cull: expected a contiguous int32 tensor of {tiles} tiles on {dev} "
+                                              "(diff_gaussian_rasterization.new_tile_cull)")
+                    # lists truncated by depth only where a frame may flag itself afterwards: unverified, not under capture
+                    cull_apply = tile_cull is not None and bool(tile_cull_apply) and not verify and not capturing and tlo == 1
+                    _C.check(lib.gsr_forward_async_culled(C.byref(s), C.byref(g), _C.ptr(geom), geom.numel(), _C.ptr(radii),
+                                                          _C.ptr(binning), binning.numel(), R, _C.ptr(img), img.numel(),
+                                                          _C.ptr(color), _C.ptr(invdepth), 1 if needs_grad else 0,
+                                                          1 if split else 0, evh, C.c_void_p(status.data_ptr()), tlo, stream,
+                                                          C.byref(count) if verify else None, _C.ptr(tile_cull),
+                                                          1 if cull_apply else 0))
+                    if cull_apply:
+                        pool.stats["culled_frames"] = pool.stats.get("culled_frames", 0) + 1
                     pool.ticket += 1
                     pool.stats["tile_local_frames"] = pool.stats.get("tile_local_frames", 0) + tlo
                     if verify:
@@ -524,18 +548,20 @@ class _RasterizeGaussians(torch.autograd.Function):
             if fold is not None:
                 fold.stats_taken = fold.stats_taken or stats is not None      # (P == 0: no rows, nothing to add)
                 fold.sh_rest_skipped = bool(skip_rest)
-        return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None, None, None, None, None)
+        return (d_means3D, d_means2D, d_dc, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None, None, None, None, None, None,
+                None)
 
 
 def rasterize_gaussians(means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, raw_activations=False, fold=None, sh_ready_event=None, forward_mode=None):
+                        raster_settings, raw_activations=False, fold=None, sh_ready_event=None, forward_mode=None,
+                        tile_cull=None, tile_cull_apply=True):
     # forward-only render (torch.no_grad(), reference render.py:49, or no input that requires grad): the library then skips
     # what only a backward would need
     tensors = (means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
     for_backward = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
     return _RasterizeGaussians.apply(means3D, means2D, dc, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, raw_activations, for_backward, fold, sh_ready_event,
-                                     forward_mode)
+                                     forward_mode, tile_cull, tile_cull_apply)
 
 
 def pair_evaluations(raster_settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
@@ -593,12 +619,16 @@ class GaussianRasterizer(nn.Module):
             return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, dc=None, raw_activations=False, *, fold=None, sh_ready_event=None, forward_mode=None):
+                cov3D_precomp=None, dc=None, raw_activations=False, *, fold=None, sh_ready_event=None, forward_mode=None,
+                tile_cull=None, tile_cull_apply=True):
         """Arguments of the reference's call (gaussian_renderer/__init__.py:90-109).  Extensions, all optional and all PER CALL
         (nothing is armed process-wide): `raw_activations=True`: `opacities`, `scales`, `rotations` are the model's RAW
         parameters; sigmoid / exp / normalize are applied inside the projection kernel and the returned gradients are w.r.t. the
         raw parameters.  `fold`: a BackwardFold (optimizer step / densification statistics / skipped dL/dsh_rest in this call's
-        backward).  `sh_ready_event`: colours wait for this event.  `forward_mode`: "exact" | "async" | "sync" for this call."""
+        backward).  `sh_ready_event`: colours wait for this event.  `forward_mode`: "exact" | "async" | "sync" for this call.
+        `tile_cull`: `new_tile_cull(...)` tensor of the VIEW being rendered (one per camera of a training set): tile lists
+        truncated by the depth each tile saturated at when the view was last rendered (include/gsr.h gsr_forward_async_culled);
+        `tile_cull_apply=False`: only keep the cut-offs up to date in this call."""
         def none_if_empty(t):
             return None if (t is None or t.numel() == 0) else t
         shs, colors_precomp, dc = none_if_empty(shs), none_if_empty(colors_precomp), none_if_empty(dc)
@@ -612,7 +642,8 @@ class GaussianRasterizer(nn.Module):
                     ((scales is not None or rotations is not None) and cov3D_precomp is not None):
                 raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         return rasterize_gaussians(means3D, means2D, dc, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, self.raster_settings, raw_activations, fold, sh_ready_event, forward_mode)
+                                   cov3D_precomp, self.raster_settings, raw_activations, fold, sh_ready_event, forward_mode,
+                                   tile_cull, tile_cull_apply)
 
 
 from .sparse_adam import SparseGaussianAdam, FusedAdam  # noqa: E402,F401   (reference train.py:37-41)

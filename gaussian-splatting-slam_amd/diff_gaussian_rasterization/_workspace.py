@@ -222,6 +222,12 @@ class Pool:
                                   "(inter-workgroup hand-off broken) - its tile lists, image and gradients are not to be trusted")
             if verified:        # "exact" mode: the count was looked at (and acted upon) before the forward returned
                 continue
+            if int(status[3]) & 0xFFFFFFFF:
+                # a tile list truncated by its depth cut-off was too short (gsr_forward_async_culled): the frame flagged itself,
+                # its backward was a no-op; the caller renders the view again (untruncated).  Nothing to learn about capacities.
+                self.stats["cull_miss_frames"] = self.stats.get("cull_miss_frames", 0) + 1
+                self.overflowed.append(ticket)
+                continue
             if (flags >> 32) & 1:
                 raise _C.GsrError("Point is filtered although prefiltered is set. This shouldn't happen!")
             if R > cap or R < 0:

@@ -96,6 +96,7 @@ class Trainer:
         self._rank1_fused = False
         self.rank1_fuse_adam = True      # exchange "sh_rank1": let the rebuilding kernel apply the SH groups' Adam step (dense HIP Adam)
         self._ticket_view = {}           # forward mode "async": rasterizer ticket -> view of the frames still unverified
+        self.tile_cull = None            # enable_tile_cull(): view -> per-tile depth cut-offs (lists truncated by depth)
         self.graph_replay = False        # enable_graph_replay(): the single-view step as ONE HIP graph launch
         self._graph = None
         self.rerun_views = 0             # ... and how many truncated frames were run again
@@ -118,6 +119,24 @@ class Trainer:
     @property
     def max_radii2D(self):
         return self.model.max_radii2D
+
+    def enable_tile_cull(self, on=True):
+        """Tile lists truncated by depth (include/gsr.h gsr_forward_async_culled): every view of the training set keeps the depth
+        each of its tiles saturated at when it was last rendered (+ a margin); the next UNVERIFIED render of the view (forward mode
+        "async": folded optimizer, one view per step, one rank) emits only the instances in front of it.  Where the scene
+        saturates early this removes most of the step's R-proportional work.  A frame whose truncation was too tight flags
+        itself - its backward, optimizer step included, is a no-op on the device - and is run again untruncated before the next
+        view is touched (the machinery of forward mode "async"): parameters, moments and statistics equal the untruncated
+        run's bit for bit (tests/test_tile_cull_gpu.py).  Verified steps only keep the cut-offs up to date."""
+        self.tile_cull = {} if on else None
+        # back-off per view: a frame that flagged itself costs a whole extra step, so the view then renders untruncated for 2, 4,
+        # ... 16 visits (its cut-offs keep being refreshed) before truncation is tried again; one clean truncated visit resets it.
+        # Where the scene changes faster than the views come round (a growing SLAM-style map) this keeps the cost at a few re-runs.
+        self._cull_wait, self._cull_penalty = {}, {}
+        # ... and a governor over all views: more than 2 flagged among 50 truncated frames (a scene that still moves fast: training
+        # from scratch with densification, config 5) switches truncation off for the next 1000 iterations, 2000 the next time, ...
+        # (a clean window halves the term again)
+        self._cull_window, self._cull_off_until, self._cull_off_len = [0, 0], -1, 1000
 
     def enable_densification(self, extent, from_iter=500, until_iter=15000, interval=100, opacity_reset_interval=3000,
                              grad_threshold=0.0002, min_opacity=0.005, seed=0, max_gaussians=None):
@@ -164,6 +183,15 @@ class Trainer:
             kw["sh_ready_event"] = ev
         return kw, fold, want_fold
 
+    def _tile_cull_of(self, v):
+        """This view's cut-off tensor (created on first use: no limit anywhere)."""
+        import diff_gaussian_rasterization as dgr
+        t = self.tile_cull.get(v)
+        if t is None:
+            cam = self.cameras[v]
+            t = self.tile_cull[v] = dgr.new_tile_cull(cam.image_height, cam.image_width, self.model.get_xyz.device)
+        return t
+
     def _eager_step(self, views, forward_mode=None):
         is_hip = self.model.get_xyz.is_cuda
         mode = None
@@ -186,6 +214,23 @@ class Trainer:
         for n, v in enumerate(views):
             cam = self.cameras[v]
             kw, fold, want_fold = self._render_kwargs(len(views), mode, unverified)
+            if self.tile_cull is not None and is_hip:
+                kw["tile_cull"] = self._tile_cull_of(v)      # (applied by unverified forwards, kept up to date by all)
+                if self.iteration < self._cull_off_until:
+                    kw["tile_cull_apply"] = False
+                elif self._cull_wait.get(v, 0) > 0:
+                    self._cull_wait[v] -= 1
+                    kw["tile_cull_apply"] = False
+                elif unverified:
+                    self._cull_penalty[v] = max(0, self._cull_penalty.get(v, 0) - 1)   # (decays with every truncated visit)
+                    self._cull_window[0] += 1
+                    if self._cull_window[0] >= 50 or self._cull_window[1] > 2:
+                        if self._cull_window[1] > 2:
+                            self._cull_off_until = self.iteration + self._cull_off_len
+                            self._cull_off_len = min(2 * self._cull_off_len, 64000)
+                        else:
+                            self._cull_off_len = max(1000, self._cull_off_len // 2)
+                        self._cull_window = [0, 0]
             pkg = self.render_fn(cam, self.model, self.pipe, self.bg, separate_sh=self.separate_sh, **kw)
             if "sh_ready_event" in kw:
                 self._pending_sh_event = None     # (that forward made its stream wait for it)
@@ -304,6 +349,10 @@ class Trainer:
                         st["step"] -= 1
             self.iteration -= 1              # ... and neither may the iteration count (densification / reset schedule)
             self.rerun_views += 1
+            if self.tile_cull is not None:   # (a truncation that was too tight, most likely: back off on this view)
+                p = self._cull_penalty[v] = min(16, max(2, 2 * self._cull_penalty.get(v, 0)))
+                self._cull_wait[v] = p
+                self._cull_window[1] += 1
             self._eager_step([v], forward_mode="exact")
         if len(self._ticket_view) > 256:      # statuses arrive in order: anything older than the newest 64 is long verified
             for t in sorted(self._ticket_view)[:-64]:
@@ -564,3 +613,8 @@ class Trainer:
             self.bucket = GradBucket(self._arena_order_params())
         if changed and self.graph_replay:
             self._drop_graph()                      # (explicitly: not left to the signature alone)
+        if changed and self.tile_cull:
+            # a densification / pruning / opacity reset moves every tile's saturation depth at once: cut-offs learnt before it would
+            # flag a third of the frames that follow (measured on config 5); every view relearns its own on its next render
+            for t in self.tile_cull.values():
+                t.fill_(-1)

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-/* 6: host_status word 0 bit 0 = radix-sort look-back time-out (was reserved; debug = 1 fails the call), gsr_debug_wave_reduce_pk;
+/* 6: host_status word 0 bit 0 = radix-sort look-back time-out (was reserved; debug = 1 fails the call), gsr_debug_wave_reduce_pk,
+ *    gsr_forward_async_culled (host_status word 0 bit 1 / word 6 = a truncated tile list was too short);
  * 5: gsr_fused_adam.dynamic + gsr_adam_set_dynamic (optimizer factors in device memory, for HIP-graph replay), gsr_l1_mean_*;
  * 4: gsr_forward_async(num_rendered_out) / gsr_forward_rerender (verified speculation), gsr_sh_rank1_*; 3: gsr_backward_adam */
 #define GSR_ABI_VERSION 6
@@ -190,6 +191,23 @@ int gsr_forward_async(const gsr_settings* s, const gsr_gaussians* g, void* geome
                       int32_t defer_color, void* sh_ready_event, uint32_t* host_status, int32_t tile_local_sort,
                       void* stream, int64_t* num_rendered_out /* host, or NULL */);
 
+/* gsr_forward_async with TILE LISTS TRUNCATED BY DEPTH (round 4).  tile_depth_cutoff: `tiles` uint32 words owned by the caller, one
+ * array per VIEW it renders repeatedly (a training set's cameras), initialised to 0xFFFFFFFF.  Every call UPDATES it: the
+ * compositing kernel leaves, per tile, the depth bits of the list entry at 1.75 x (+ 48) the position of the deepest one any pixel
+ * of the tile needed before it saturated (T < 1e-4) - 0xFFFFFFFF if a pixel never saturated.  With apply != 0 (honoured only for an
+ * unverified frame, num_rendered_out == NULL, in the tile-local binning form, debug off) the array is also USED: a (tile, Gaussian)
+ * instance whose depth lies behind its tile's cut-off is neither counted nor emitted - the tile's depth-ordered list loses its
+ * tail.  If every pixel of a truncated tile still saturates inside its list, image, depth, final_T, n_contrib and all gradients
+ * are those of the untruncated frame bit for bit (the loop never reached the missing tail).  If one does not, the frame flags
+ * itself: status word 0 bit 1 on the device - gsr_backward / gsr_backward_adam are then NO-OPS, as for a frame beyond the capacity -
+ * and word 6 of host_status (clear it before the call; final once an event recorded behind the call has completed); the caller
+ * renders that view again with apply = 0.  Where a scene saturates early (dense captures) this removes most of the R-proportional
+ * work of the step: emission, both tile-sort passes, per-tile ordering, the gradient-record gather. */
+int gsr_forward_async_culled(const gsr_settings* s, const gsr_gaussians* g, void* geometry_state, size_t geometry_bytes,
+                             int32_t* radii, void* binning_state, size_t binning_bytes, int64_t capacity, void* image_state,
+                             size_t image_bytes, float* out_color, float* out_invdepth, int32_t for_backward,
+                             int32_t defer_color, void* sh_ready_event, uint32_t* host_status, int32_t tile_local_sort,
+                             void* stream, int64_t* num_rendered_out, uint32_t* tile_depth_cutoff, int32_t apply);
 /* Phase 2 once more on the state a gsr_forward_async call with the same `s`, `g`, geometry / image state and tile_local_sort
  * left behind, for a (larger) binning state of `capacity` >= the count that call reported: instance emission, tile sort,
  * ranges, per-tile ordering, compositing.  Stream-ordered behind the first attempt; overwrites its outputs. */
