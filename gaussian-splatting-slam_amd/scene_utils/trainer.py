@@ -137,6 +137,7 @@ class Trainer:
         # from scratch with densification, config 5) switches truncation off for the next 1000 iterations, 2000 the next time, ...
         # (a clean window halves the term again)
         self._cull_window, self._cull_off_until, self._cull_off_len = [0, 0], -1, 1000
+        self.cull_adaptive = True        # (False: truncate every eligible frame - the sweeps want every frame tried)
 
     def enable_densification(self, extent, from_iter=500, until_iter=15000, interval=100, opacity_reset_interval=3000,
                              grad_threshold=0.0002, min_opacity=0.005, seed=0, max_gaussians=None):
@@ -216,7 +217,9 @@ class Trainer:
             kw, fold, want_fold = self._render_kwargs(len(views), mode, unverified)
             if self.tile_cull is not None and is_hip:
                 kw["tile_cull"] = self._tile_cull_of(v)      # (applied by unverified forwards, kept up to date by all)
-                if self.iteration < self._cull_off_until:
+                if not self.cull_adaptive:
+                    pass
+                elif self.iteration < self._cull_off_until:
                     kw["tile_cull_apply"] = False
                 elif self._cull_wait.get(v, 0) > 0:
                     self._cull_wait[v] -= 1
