@@ -42,138 +42,198 @@ static SsimWindow make_window() {
 // XCD-aware tile order.  Consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so with the natural
 // (x, y, plane) order two x-adjacent tiles - which share a 10-pixel halo - never share an L2 and every halo is fetched from
 // the fabric again (PMC: k_ssim_bwd read 339 MB for 125 MB of input).  Workgroup b instead takes tile
-// (b % 8) * ceil(n / 8) + b / 8: each XCD walks ONE contiguous strip of the (plane, y, x) order and keeps its halos in L2.
-// The launch is 1-D with 8 * ceil(n / 8) workgroups; the few past the end return at once.
+// (b % 8) * ceil(n / 8) + (b / 8) * tpw: each XCD walks ONE contiguous strip of the (plane, y, x) order and keeps its halos in
+// L2.  The launch is 1-D with 8 * ceil(ceil(n / 8) / tpw) workgroups; the few past the end return at once.
 #define SSIM_XCDS 8
-struct SsimTile { int tx, ty, plane; long long lin; bool valid; };
-__device__ __forceinline__ SsimTile ssim_tile(int gx, int gy, int planes) {
+// A workgroup of the FORWARD walks `tpw` consecutive tiles of its strip and keeps the NEXT tile's halo in flight (registers) while
+// it convolves the current one: all workgroups of a launch start together and take the same time, so their load phases and their
+// compute phases coincide on a CU (round 4 PMC: half of all wave cycles parked).  With the halo of the next tile in flight, the L1
+// term moved into the horizontal pass and the tile sums reduced per wave, a tile costs two barriers instead of seven and the
+// parked share drops from 48 % to 30 % of the wave cycles: 69 -> 65.5 us at 1080p, at five waves per SIMD instead of six (88
+// VGPRs).  The same treatment of the backward (19 more registers: 8 -> 5 waves per SIMD) ran 53 -> 62-72 us in every variant
+// tried (double-buffered LDS, 4 / 5 / 6 waves, 1 / 2 / 4 / 8 tiles): it stays one tile per workgroup.  What bounds both after
+// that is the LDS pipe (ACTIVE_INST_LDS 63 % of the kernel per CU beside 45 % VALU), `gpurun_out/r5c`.
+#define NTRIP ((SHY * SH + 255) / 256)   // halo elements per thread
+#ifndef SSIM_FWD_WAVES
+#define SSIM_FWD_WAVES 5                 // registers (88, with the next halo in flight) admit five waves per SIMD; LDS six
+#endif
+struct SsimTile { int x0, y0; size_t plane; };
+struct SsimWalk { long long first; int count; };   // tiles [first, first + count) of the (plane, y, x) order
+__device__ __forceinline__ SsimWalk ssim_walk(int gx, int gy, int planes, int tpw) {
   const long long n = (long long)gx * gy * planes;
   const long long per = (n + SSIM_XCDS - 1) / SSIM_XCDS;
-  const long long lin = (long long)(blockIdx.x % SSIM_XCDS) * per + blockIdx.x / SSIM_XCDS;
+  const long long strip = blockIdx.x % SSIM_XCDS, off = (long long)(blockIdx.x / SSIM_XCDS) * tpw;
+  SsimWalk w;
+  w.first = strip * per + off;
+  long long last = strip * per + (off + tpw < per ? off + tpw : per);
+  if (last > n) last = n;
+  w.count = last > w.first ? (int)(last - w.first) : 0;
+  return w;
+}
+__device__ __forceinline__ SsimTile ssim_tile_at(long long lin, int gx, int gy, int H, int W) {
+  const int plane = (int)(lin / ((long long)gx * gy));
+  const int rem = (int)(lin - (long long)plane * gx * gy);
+  const int ty = rem / gx;
   SsimTile t;
-  t.lin = lin;
-  t.valid = lin < n;
-  const long long l = t.valid ? lin : 0;
-  t.plane = (int)(l / ((long long)gx * gy));
-  const int rem = (int)(l - (long long)t.plane * gx * gy);
-  t.ty = rem / gx;
-  t.tx = rem - t.ty * gx;
+  t.x0 = (rem - ty * gx) * ST;
+  t.y0 = ty * STY;
+  t.plane = (size_t)plane * H * W;
   return t;
 }
-static inline unsigned ssim_grid(int gx, int gy, int planes) {
+static inline unsigned ssim_grid(int gx, int gy, int planes, int tpw) {
   const long long n = (long long)gx * gy * planes;
-  return (unsigned)(((n + SSIM_XCDS - 1) / SSIM_XCDS) * SSIM_XCDS);
+  const long long per = (n + SSIM_XCDS - 1) / SSIM_XCDS;
+  return (unsigned)(((per + tpw - 1) / tpw) * SSIM_XCDS);
+}
+// tiles per workgroup of the forward: the pipeline pays once the launch runs in several rounds of resident workgroups
+static inline int ssim_fwd_tpw(int gx, int gy, int planes) {
+  static const int forced = getenv("GSR_SSIM_TPW") ? atoi(getenv("GSR_SSIM_TPW")) : 0;
+  if (forced > 0) return forced;
+  return (long long)gx * gy * planes >= 4096 ? 2 : 1;
 }
 
 // `partials` != NULL: the kernel also reduces sum(ssim) and sum(|img1-img2|) over its tile into partials[2*block .. +1]
 // (fixed in-block order; the host adds the per-block pairs in index order -> deterministic), which is all the fused
 // L1 + D-SSIM training loss needs; `ssim_map` may then be NULL.
-__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int planes, float C1, float C2, SsimWindow win,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSIM_FWD_WAVES, SSIM_FWD_WAVES))) void k_ssim_fwd(int H, int W, int planes, float C1, float C2, SsimWindow win,
                                                   const float* __restrict__ img1, const float* __restrict__ img2,
                                                   float* __restrict__ ssim_map, float* __restrict__ dm_dmu1,
                                                   float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
-                                                  float* __restrict__ partials) {
+                                                  float* __restrict__ partials, int tpw) {
   __shared__ float sx[SHY][SH + 1], sy[SHY][SH + 1];
   __shared__ float hm[5][SHY][ST + 1];
-  const int tid = threadIdx.x;
-  const SsimTile tile = ssim_tile((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
-  if (!tile.valid) return;                         // block-uniform
-  const int x0 = tile.tx * ST, y0 = tile.ty * STY;
-  const size_t plane = (size_t)tile.plane * H * W;
-  // halo load; (row, column) of flat index i is carried from trip to trip (i += 256 = 6 rows + 4 columns at SH = 42)
-  {
+  __shared__ float wsum[4][2];                     // per wave: (ssim sum, L1 sum) of the tile just finished
+  const int tid0 = threadIdx.x;
+  const int gxn = (W + ST - 1) / ST, gyn = (H + STY - 1) / STY;
+  const SsimWalk walk = ssim_walk(gxn, gyn, planes, tpw);
+  if (walk.count <= 0) return;                     // block-uniform
+  // halo of one tile: NTRIP elements per thread; (row, column) of flat index i is carried from trip to trip (i += 256 = 6 rows +
+  // 4 columns at SH = 42)
+  float ra[NTRIP], rb[NTRIP];
+  auto fetch = [&](long long lin, int tid) {
+    const SsimTile t = ssim_tile_at(lin, gxn, gyn, H, W);
     int r = tid / SH, c = tid - r * SH;
-    for (int i = tid; i < SHY * SH; i += 256) {
-      const int gy = y0 + r - SR, gx = x0 + c - SR;
+#pragma unroll
+    for (int k = 0; k < NTRIP; k++) {
+      const int gy = t.y0 + r - SR, gx = t.x0 + c - SR;
       float a = 0.f, b = 0.f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        a = img1[plane + (size_t)gy * W + gx];
-        b = img2[plane + (size_t)gy * W + gx];
+      if (tid + 256 * k < SHY * SH && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        a = (img1 + t.plane)[gy * W + gx];           // uniform plane base + 32-bit offset (H * W < 2^31, checked by the host)
+        b = (img2 + t.plane)[gy * W + gx];
       }
-      sx[r][c] = a;
-      sy[r][c] = b;
+      ra[k] = a;
+      rb[k] = b;
       r += 256 / SH; c += 256 % SH;
       if (c >= SH) { c -= SH; r++; }
     }
-  }
-  __syncthreads();
-  // horizontal pass: SH rows x ST columns, FOUR adjacent columns per thread: the 14 taps they share are read from LDS once
-  // (sliding window) instead of 11 per output
-  for (int i = tid; i < SHY * (ST / 4); i += 256) {
-    const int r = i / (ST / 4), c0 = (i - r * (ST / 4)) * 4;
-    float xa[14], ya[14];
+  };
+  fetch(walk.first, tid0);
+  for (int ti = 0; ti < walk.count; ti++) {
+    // the thread index is re-read per tile behind an opaque move: everything derived from it (LDS and image offsets of five code
+    // sections) would otherwise be hoisted out of this loop and held in registers across it (125 VGPRs instead of 80)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const long long lin = walk.first + ti;
+    const SsimTile tile = ssim_tile_at(lin, gxn, gyn, H, W);
+    const int x0 = tile.x0, y0 = tile.y0;
+    const size_t plane = tile.plane;
+    {
+      int r = tid / SH, c = tid - r * SH;
 #pragma unroll
-    for (int k = 0; k < 14; k++) { xa[k] = sx[r][c0 + k]; ya[k] = sy[r][c0 + k]; }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 11; k++) {
-        const float w = win.g[k], a = xa[j + k], b = ya[j + k];
-        m1 += w * a; m2 += w * b; s11 += w * a * a; s22 += w * b * b; s12 += w * a * b;
+      for (int k = 0; k < NTRIP; k++) {
+        if (tid + 256 * k < SHY * SH) { sx[r][c] = ra[k]; sy[r][c] = rb[k]; }
+        r += 256 / SH; c += 256 % SH;
+        if (c >= SH) { c -= SH; r++; }
       }
-      hm[0][r][c0 + j] = m1; hm[1][r][c0 + j] = m2; hm[2][r][c0 + j] = s11; hm[3][r][c0 + j] = s22; hm[4][r][c0 + j] = s12;
     }
-  }
-  __syncthreads();
-  // vertical pass + SSIM: each thread owns column c and FOUR adjacent rows (14 shared taps per moment)
-  float acc_ssim = 0.f, acc_l1 = 0.f;
-  {
-    const int c = tid & (ST - 1), r0 = (tid / ST) * RPT;
-    float col[5][RPT + 10];
+    __syncthreads();
+    if (ti > 0 && tid == 0 && partials) {            // the previous tile's sums (its waves wrote them before this barrier)
+      partials[2 * (size_t)(lin - 1)] = (wsum[0][0] + wsum[1][0]) + (wsum[2][0] + wsum[3][0]);
+      partials[2 * (size_t)(lin - 1) + 1] = (wsum[0][1] + wsum[1][1]) + (wsum[2][1] + wsum[3][1]);
+    }
+    if (ti + 1 < walk.count) fetch(lin + 1, tid);    // in flight while this tile is convolved
+    // horizontal pass: SH rows x ST columns, FOUR adjacent columns per thread: the 14 taps they share are read from LDS once
+    // (sliding window) instead of 11 per output.  The L1 term is summed here too (taps 5..8 of an interior row ARE the item's
+    // four pixels): the staged images are then dead behind this pass and the next tile's may land while the vertical pass runs.
+    float acc_ssim = 0.f, acc_l1 = 0.f;
+    for (int i = tid; i < SHY * (ST / 4); i += 256) {
+      const int r = i / (ST / 4), c0 = (i - r * (ST / 4)) * 4;
+      float xa[14], ya[14];
 #pragma unroll
-    for (int q = 0; q < 5; q++)
+      for (int k = 0; k < 14; k++) { xa[k] = sx[r][c0 + k]; ya[k] = sy[r][c0 + k]; }
+      if (r >= SR && r < SR + STY && y0 + r - SR < H) {
 #pragma unroll
-      for (int k = 0; k < RPT + 10; k++) col[q][k] = hm[q][r0 + k][c];
-#pragma unroll
-    for (int j = 0; j < RPT; j++) {
-      const int r = r0 + j;
-      const int gy = y0 + r, gx = x0 + c;
-      if (gy >= H || gx >= W) continue;
-      float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 11; k++) {
-        const float w = win.g[k];
-        mu1 += w * col[0][j + k]; mu2 += w * col[1][j + k]; e11 += w * col[2][j + k];
-        e22 += w * col[3][j + k]; e12 += w * col[4][j + k];
+        for (int j = 0; j < 4; j++)
+          if (x0 + c0 + j < W) acc_l1 += fabsf(xa[SR + j] - ya[SR + j]);
       }
-      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-      const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
-      const float A = 2.f * mu12 + C1, B = 2.f * sigma12 + C2;
-      const float Cc = mu1_sq + mu2_sq + C1, D = sigma1_sq + sigma2_sq + C2;
-      // (v_rcp_f32, 1 ulp: three IEEE divisions per pixel-channel were ~10 % of this kernel's instructions)
-      const float rCc = __builtin_amdgcn_rcpf(Cc), rD = __builtin_amdgcn_rcpf(D);
-      const float inv = rCc * rD;
-      const float m = A * B * inv;
-      const size_t o = plane + (size_t)gy * W + gx;
-      if (ssim_map) ssim_map[o] = m;
-      acc_ssim += m;
-      acc_l1 += fabsf(sx[r + SR][c + SR] - sy[r + SR][c + SR]);
-      if (dm_dmu1) {
-        // partials holding E[xx], E[yy], E[xy] fixed (sigma's depend on mu1 through -mu1^2, -mu1*mu2)
-        dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - m * 2.f * mu1 * rCc + m * 2.f * mu1 * rD;
-        dm_dsigma1_sq[o] = -m * rD;
-        dm_dsigma12[o] = 2.f * A * inv;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+          const float w = win.g[k], a = xa[j + k], b = ya[j + k];
+          m1 += w * a; m2 += w * b; s11 += w * a * a; s22 += w * b * b; s12 += w * a * b;
+        }
+        hm[0][r][c0 + j] = m1; hm[1][r][c0 + j] = m2; hm[2][r][c0 + j] = s11; hm[3][r][c0 + j] = s22; hm[4][r][c0 + j] = s12;
       }
+    }
+    __syncthreads();
+    // vertical pass + SSIM: each thread owns column c and RPT adjacent rows (RPT + 10 shared taps per moment)
+    {
+      const int c = tid & (ST - 1), r0 = (tid / ST) * RPT;
+      float col[5][RPT + 10];
+#pragma unroll
+      for (int q = 0; q < 5; q++)
+#pragma unroll
+        for (int k = 0; k < RPT + 10; k++) col[q][k] = hm[q][r0 + k][c];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        const int r = r0 + j;
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy >= H || gx >= W) continue;
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+          const float w = win.g[k];
+          mu1 += w * col[0][j + k]; mu2 += w * col[1][j + k]; e11 += w * col[2][j + k];
+          e22 += w * col[3][j + k]; e12 += w * col[4][j + k];
+        }
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
+        const float A = 2.f * mu12 + C1, B = 2.f * sigma12 + C2;
+        const float Cc = mu1_sq + mu2_sq + C1, D = sigma1_sq + sigma2_sq + C2;
+        // (v_rcp_f32, 1 ulp: three IEEE divisions per pixel-channel were ~10 % of this kernel's instructions)
+        const float rCc = __builtin_amdgcn_rcpf(Cc), rD = __builtin_amdgcn_rcpf(D);
+        const float inv = rCc * rD;
+        const float m = A * B * inv;
+        const size_t o = plane + (size_t)gy * W + gx;
+        if (ssim_map) ssim_map[o] = m;
+        acc_ssim += m;
+        if (dm_dmu1) {
+          // partials holding E[xx], E[yy], E[xy] fixed (sigma's depend on mu1 through -mu1^2, -mu1*mu2)
+          dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - m * 2.f * mu1 * rCc + m * 2.f * mu1 * rD;
+          dm_dsigma1_sq[o] = -m * rD;
+          dm_dsigma12[o] = 2.f * A * inv;
+        }
+      }
+    }
+    if (partials) {
+      // fixed order: a halving tree inside each wave, the four wave sums added as (0 + 1) + (2 + 3) by thread 0 behind the next
+      // barrier of the workgroup (the next tile's first one, or the one below); the finalize kernel adds the tiles in index order
+#pragma unroll
+      for (int sft = 32; sft > 0; sft >>= 1) {
+        acc_ssim += __shfl_down(acc_ssim, sft, 64);
+        acc_l1 += __shfl_down(acc_l1, sft, 64);
+      }
+      if ((tid & 63) == 0) { wsum[tid >> 6][0] = acc_ssim; wsum[tid >> 6][1] = acc_l1; }
     }
   }
   if (partials) {
-    __syncthreads();                               // hm is free now: reuse it for the block reduction
-    float* red = &hm[0][0][0];
-    red[tid] = acc_ssim;
-    red[256 + tid] = acc_l1;
     __syncthreads();
-    for (int sft = 128; sft > 0; sft >>= 1) {
-      if (tid < sft) {
-        red[tid] += red[tid + sft];
-        red[256 + tid] += red[256 + tid + sft];
-      }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      const size_t b = (size_t)tile.lin;           // (plane, y, x) order: the host adds the pairs in this fixed order
-      partials[2 * b] = red[0];
-      partials[2 * b + 1] = red[256];
+    if (tid0 == 0) {
+      const size_t lin = (size_t)(walk.first + walk.count - 1);
+      partials[2 * lin] = (wsum[0][0] + wsum[1][0]) + (wsum[2][0] + wsum[3][0]);
+      partials[2 * lin + 1] = (wsum[0][1] + wsum[1][1]) + (wsum[2][1] + wsum[3][1]);
     }
   }
 }
@@ -193,10 +253,12 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int planes, Ssim
   // that spends 60 % of its wave cycles waiting on memory (61 -> 54 us at 1080p).
   __shared__ float sa[3][SHY][SH + 1];
   const int tid = threadIdx.x;
-  const SsimTile tile = ssim_tile((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
-  if (!tile.valid) return;                         // block-uniform
-  const int x0 = tile.tx * ST, y0 = tile.ty * STY;
-  const size_t plane = (size_t)tile.plane * H * W;
+  const int gxn = (W + ST - 1) / ST, gyn = (H + STY - 1) / STY;
+  const SsimWalk walk = ssim_walk(gxn, gyn, planes, 1);
+  if (walk.count <= 0) return;                     // block-uniform
+  const SsimTile tile = ssim_tile_at(walk.first, gxn, gyn, H, W);
+  const int x0 = tile.x0, y0 = tile.y0;
+  const size_t plane = tile.plane;
   if (upstream) {                                  // scalar dL/dloss lives on the device: no host round trip
     const float u = upstream[0];
     g_const *= u;
@@ -280,8 +342,9 @@ int gsr_fused_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
-  GSR_LAUNCH("ssim_fwd", k_ssim_fwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, C1, C2, win, img1, img2, ssim_map, dm_dmu1,
-             dm_dsigma1_sq, dm_dsigma12, (float*)nullptr);
+  const int tpw = ssim_fwd_tpw(grid.x, grid.y, planes);
+  GSR_LAUNCH("ssim_fwd", k_ssim_fwd, dim3(ssim_grid(grid.x, grid.y, planes, tpw)), dim3(256), 0, st, H, W, planes, C1, C2, win, img1, img2,
+             ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, tpw);
   return gsr_launch_status("ssim forward launch");
 }
 
@@ -292,29 +355,46 @@ int64_t gsr_fused_loss_blocks(int32_t planes, int32_t H, int32_t W) {
   return (int64_t)((W + ST - 1) / ST) * ((H + STY - 1) / STY) * planes;
 }
 
-// one workgroup adds the per-block partial sums in a fixed order and forms the scalar loss
+// one workgroup adds the per-tile partial sums in a fixed order and forms the scalar loss: thread t takes tiles t, t + 1024, ...
+// (four loads in flight), a halving tree inside each wave, the sixteen wave sums through LDS and one more tree in wave 0 - one
+// barrier instead of the ten of a workgroup-wide LDS tree (8.5 -> ~5 us, most of what is left is the launch itself)
 #define LOSS_FIN_THREADS 1024
 __global__ __launch_bounds__(LOSS_FIN_THREADS) void k_loss_finalize(const float* __restrict__ partials, long long nblk,
                                                                     float lambda, float inv_n, float* __restrict__ loss) {
-  __shared__ float red[2 * LOSS_FIN_THREADS];
+  __shared__ float red[2][LOSS_FIN_THREADS / 64];
   const float2* pairs = reinterpret_cast<const float2*>(partials);   // (ssim sum, L1 sum) per tile, 8-B aligned
   float a = 0.f, b = 0.f;
-  for (long long i = threadIdx.x; i < nblk; i += LOSS_FIN_THREADS) {
+  long long i = threadIdx.x;
+  for (; i + 3 * LOSS_FIN_THREADS < nblk; i += 4 * LOSS_FIN_THREADS) {
+    const float2 v0 = pairs[i], v1 = pairs[i + LOSS_FIN_THREADS], v2 = pairs[i + 2 * LOSS_FIN_THREADS],
+                 v3 = pairs[i + 3 * LOSS_FIN_THREADS];
+    a += v0.x; b += v0.y;
+    a += v1.x; b += v1.y;
+    a += v2.x; b += v2.y;
+    a += v3.x; b += v3.y;
+  }
+  for (; i < nblk; i += LOSS_FIN_THREADS) {
     const float2 v = pairs[i];
     a += v.x;
     b += v.y;
   }
-  red[threadIdx.x] = a;
-  red[LOSS_FIN_THREADS + threadIdx.x] = b;
-  __syncthreads();
-  for (int sft = LOSS_FIN_THREADS / 2; sft > 0; sft >>= 1) {          // fixed tree: deterministic
-    if ((int)threadIdx.x < sft) {
-      red[threadIdx.x] += red[threadIdx.x + sft];
-      red[LOSS_FIN_THREADS + threadIdx.x] += red[LOSS_FIN_THREADS + threadIdx.x + sft];
-    }
-    __syncthreads();
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) {
+    a += __shfl_down(a, sft, 64);
+    b += __shfl_down(b, sft, 64);
   }
-  if (threadIdx.x == 0) loss[0] = (1.0f - lambda) * (red[LOSS_FIN_THREADS] * inv_n) + lambda * (1.0f - red[0] * inv_n);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    a = threadIdx.x < LOSS_FIN_THREADS / 64 ? red[0][threadIdx.x] : 0.f;
+    b = threadIdx.x < LOSS_FIN_THREADS / 64 ? red[1][threadIdx.x] : 0.f;
+#pragma unroll
+    for (int sft = LOSS_FIN_THREADS / 128; sft > 0; sft >>= 1) {
+      a += __shfl_down(a, sft, 64);
+      b += __shfl_down(b, sft, 64);
+    }
+    if (threadIdx.x == 0) loss[0] = (1.0f - lambda) * (b * inv_n) + lambda * (1.0f - a * inv_n);
+  }
 }
 
 int gsr_fused_l1_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, float C2, float lambda_dssim,
@@ -328,8 +408,9 @@ int gsr_fused_l1_ssim_forward(int32_t planes, int32_t H, int32_t W, float C1, fl
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
-  GSR_LAUNCH("loss_fwd", k_ssim_fwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, C1, C2, win, img1, img2, (float*)nullptr, dm_dmu1,
-             dm_dsigma1_sq, dm_dsigma12, partials);
+  const int tpw = ssim_fwd_tpw(grid.x, grid.y, planes);
+  GSR_LAUNCH("loss_fwd", k_ssim_fwd, dim3(ssim_grid(grid.x, grid.y, planes, tpw)), dim3(256), 0, st, H, W, planes, C1, C2, win, img1, img2,
+             (float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, partials, tpw);
   const long long nblk = (long long)grid.x * grid.y * grid.z;
   const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
   GSR_LAUNCH("loss_finalize", k_loss_finalize, dim3(1), dim3(LOSS_FIN_THREADS), 0, st, (const float*)partials, nblk, lambda_dssim,
@@ -349,7 +430,7 @@ int gsr_fused_l1_ssim_backward(int32_t planes, int32_t H, int32_t W, float lambd
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
   const float inv_n = 1.0f / ((float)planes * (float)H * (float)W);
-  GSR_LAUNCH("loss_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, win, img1, img2, (const float*)nullptr,
+  GSR_LAUNCH("loss_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes, 1)), dim3(256), 0, st, H, W, planes, win, img1, img2, (const float*)nullptr,
              -lambda_dssim * inv_n, (1.0f - lambda_dssim) * inv_n, upstream, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
              dL_dimg1);
   return gsr_launch_status("fused loss backward launch");
@@ -367,7 +448,7 @@ int gsr_fused_ssim_backward(int32_t planes, int32_t H, int32_t W, const float* i
   static const SsimWindow win = make_window();
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((W + ST - 1) / ST, (H + STY - 1) / STY, planes);
-  GSR_LAUNCH("ssim_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes)), dim3(256), 0, st, H, W, planes, win, img1, img2, dL_dmap, 0.f, 0.f,
+  GSR_LAUNCH("ssim_bwd", k_ssim_bwd, dim3(ssim_grid(grid.x, grid.y, planes, 1)), dim3(256), 0, st, H, W, planes, win, img1, img2, dL_dmap, 0.f, 0.f,
              (const float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
   return gsr_launch_status("ssim backward launch");
 }

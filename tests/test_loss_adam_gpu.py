@@ -11,7 +11,8 @@ from oracle import loss_oracle as losses
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape", [(3, 40, 52), (1, 3, 67, 33), (3, 1080 // 4, 1920 // 4), (2, 3, 16, 16)])
+# (3, 601, 1203): 4332 tiles, past the 4096 at which a forward workgroup walks two tiles with the next halo in flight
+@pytest.mark.parametrize("shape", [(3, 40, 52), (1, 3, 67, 33), (3, 1080 // 4, 1920 // 4), (2, 3, 16, 16), (3, 601, 1203)])
 def test_fused_ssim_matches_reference_ssim(shape):
     from fused_ssim import fused_ssim
     gen = torch.Generator().manual_seed(sum(shape))
@@ -98,7 +99,7 @@ def test_sparse_adam_touches_only_visible_rows():
         assert torch.equal(d.detach().cpu()[inv], p0[inv])       # invisible rows bit-identical
 
 
-@pytest.mark.parametrize("shape,lam", [((3, 67, 45), 0.2), ((3, 270, 480), 0.2), ((3, 33, 32), 0.7)])
+@pytest.mark.parametrize("shape,lam", [((3, 67, 45), 0.2), ((3, 270, 480), 0.2), ((3, 33, 32), 0.7), ((3, 601, 1203), 0.2)])
 def test_fused_l1_ssim_loss_matches_reference_loss(shape, lam):
     """The fused training loss against reference train.py:114-121 evaluated with the pure-PyTorch l1_loss / ssim restatements
     (float64 on the CPU), value and gradient."""
