@@ -994,6 +994,310 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// (round 4) k_render_bwd_tile_mx: the same walk, the per-(tile, Gaussian) sums taken by the MATRIX pipe.
+//
+// What the cross-lane reduction computes is a contraction: for one list entry, the ten record values are
+//     sum over the tile's 256 pixels of  h(p) * {1, dx, dy, dx^2, dx dy, dy^2}   and   w(p) * dL/dC_c(p),
+// and with d = mean - pixel the first six are a fixed linear map (applied once per entry) of the moments of h against the PIXEL
+// basis {1, X, Y, X^2, XY, Y^2} - which does not depend on the entry and is separable in X and Y.  A lane owns pixel
+// (X, Y) = (x7 + 8 (s & 1), y7 + 8 (s >> 1)), s = sub-block, x7 = lane & 7, y7 = lane >> 3; v_mfma_f32_16x16x4_f32 reads ONE
+// f32 per lane as A[i = lane & 15][k = lane >> 4] (an exact k-ordered fma chain, MI355X_MICROARCH.md "FP32-input MFMA"), so with
+//   stage 1   D1[i][j] += h_s(i, k) * B_s[k][j]      one MFMA per blended sub-block, A = the lane's h itself (no accumulation
+//                                                    instructions at all), B_s = the Y-side basis of sub-block s (constants)
+//             D1[i][5 + c] += C_c(i, k)              one MFMA per colour channel: the lane's sum of w * dL/dC_c over its pixels
+//   stage 2   D2[i'][j] = sum_i G[i'][i] * D1[i][j]  four MFMAs (D1's registers ARE the B operands: row = 4 (lane >> 4) + reg),
+//                                                    G = the X-side basis
+// D2 holds every product moment: the 27-instruction v_permlane / DPP tree, its nine zeroing moves and six of the eight
+// accumulation instructions per blended sub-block become 4 + 3 + (blended sub-blocks) MFMAs, each of which holds the vector issue
+// port for 8 cycles (two plain instructions) and otherwise runs beside the other waves' VALU work.  Coordinates are taken about
+// the tile centre (|X'|, |Y'| <= 7.5, all basis values exact in f32) to keep the cancellation of the final map small:
+//   X' = Xi' + Xs',  Xi' = (i & 7) - 3.5, Xs' = 8 (s & 1) - 4;     Y' = Yi' + Yks',  Yi' = (i >> 3) - 0.5, Yks' = 2 k + 8 (s >> 1) - 7
+//   columns j: 0: 1, 1: Yks', 2: Xs', 3: Yks'^2, 4: Xs' Yks', 5..8: colour / inverse-depth sums;  rows i': 0: 1, 1: Xi', 2: Yi',
+//   3: Xi'^2, 4: Xi' Yi'   (Xs'^2 = 16 and Yi'^2 = 1/4 are constants).
+// Lanes 0..2 store rows 0..3 of columns 0..2 (one ds_write_b128), lanes 3..8 and 16 one float each: 19 floats per entry in LDS; once
+// per batch lane j turns entry j's 19 numbers into its gradient record (gsr_mx_record) and stores it at the emission slot.
+// Every sum is still taken in a fixed order (bitwise reproducible); it is a DIFFERENT order than the swap tree's, so this form agrees
+// with the other two to rounding, not bit for bit (tests: parity against the float64 oracle at the same bar, and the basis / lane maps
+// against exact integer data, tests/test_parity_gpu.py::test_matrix_pipe_reduction_primitive).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float gsr_f4v __attribute__((ext_vector_type(4)));
+#define GSR_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define GSR_MX_SLOT_F4 5            // 19 floats per entry, padded to 80 B
+
+struct gsr_mx_basis {
+  float Bs[4];   // stage 1, B operand of sub-block s:  B_s[k = lane >> 4][j = lane & 15]
+  float Bc[4];   // stage 1, B operand of colour channel c: 1 in column 5 + c
+  float G[4];    // stage 2, A operand of step r:  G[i' = lane & 15][i = 4 (lane >> 4) + r]
+  int qofs;      // byte offset of this lane's piece inside an entry's LDS slot (lanes 0..2: 16 lane; 3..8: 48 + 4 (lane - 3); 16: 72)
+  bool lane_a, lane_b;
+};
+
+__device__ __forceinline__ void gsr_mx_basis_init(const int lane, gsr_mx_basis& K) {
+  const int j = lane & 15, k = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const float yks = (float)(2 * k + 8 * (s >> 1) - 7), xs = (float)(8 * (s & 1) - 4);
+    K.Bs[s] = j == 0 ? 1.0f : j == 1 ? yks : j == 2 ? xs : j == 3 ? yks * yks : j == 4 ? xs * yks : 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) K.Bc[c] = j == 5 + c ? 1.0f : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = 4 * k + r;
+    const float xi = (float)(i & 7) - 3.5f, yi = (float)(i >> 3) - 0.5f;
+    K.G[r] = j == 0 ? 1.0f : j == 1 ? xi : j == 2 ? yi : j == 3 ? xi * xi : j == 4 ? xi * yi : 0.0f;
+  }
+  K.qofs = lane < 3 ? 16 * lane : lane < 9 ? 48 + 4 * (lane - 3) : 72;
+  K.lane_a = lane < 3;
+  K.lane_b = ((0x101F8ull >> lane) & 1ull) != 0ull;   // lanes 3..8 and 16
+}
+
+// stage 2 + the entry's 19 numbers into its LDS slot (slot = base of the entry's 80 bytes)
+__device__ __forceinline__ void gsr_mx_finish(const gsr_f4v D1, const gsr_mx_basis& K, char* slot) {
+  const gsr_f4v zero = {0.f, 0.f, 0.f, 0.f};
+  gsr_f4v D2 = GSR_MFMA4(K.G[0], D1[0], zero);
+  D2 = GSR_MFMA4(K.G[1], D1[1], D2);
+  D2 = GSR_MFMA4(K.G[2], D1[2], D2);
+  D2 = GSR_MFMA4(K.G[3], D1[3], D2);
+  char* dst = slot + K.qofs;
+  if (K.lane_a) *reinterpret_cast<float4*>(dst) = make_float4(D2[0], D2[1], D2[2], D2[3]);
+  if (K.lane_b) *reinterpret_cast<float*>(dst) = D2[0];
+}
+
+// an entry's 19 numbers -> its gradient record; (mux, muy) = the Gaussian's 2-D mean relative to the tile CENTRE (tile origin + 7.5)
+__device__ __forceinline__ void gsr_mx_record(const float4 q0, const float4 q1, const float4 q2, const float4 q3, const float4 q4,
+                                              const float mux, const float muy, float4& o0, float4& o1, float4& o2) {
+  // q0 = column 0 (1): rows (1, Xi', Yi', Xi'^2); q1 = column 1 (Yks'); q2 = column 2 (Xs'); q3 = (Q[1][Yks'^2], Q[1][Xs'Yks'], c0, c1);
+  // q4 = (c2, c3, Q[Xi'Yi'][1], -)
+  const float M00 = q0.x;
+  const float M10 = q0.y + q2.x;                                   // sum h X'
+  const float M01 = q0.z + q1.x;                                   // sum h Y'
+  const float M20 = __builtin_fmaf(16.0f, M00, __builtin_fmaf(2.0f, q2.y, q0.w));
+  const float M02 = __builtin_fmaf(0.25f, M00, __builtin_fmaf(2.0f, q1.z, q3.x));
+  const float M11 = (q1.y + q4.z) + (q3.y + q2.z);
+  // d = mean - pixel = mu - X'
+  o0.x = __builtin_fmaf(mux, M00, -M10);
+  o0.y = __builtin_fmaf(muy, M00, -M01);
+  o0.z = __builtin_fmaf(mux, __builtin_fmaf(mux, M00, -2.0f * M10), M20);
+  o0.w = __builtin_fmaf(mux, __builtin_fmaf(muy, M00, -M01), __builtin_fmaf(-muy, M10, M11));
+  o1.x = __builtin_fmaf(muy, __builtin_fmaf(muy, M00, -2.0f * M01), M02);
+  o1.y = M00;
+  o1.z = q3.z;
+  o1.w = q3.w;
+  o2.x = q4.x;
+  o2.y = q4.y;
+  o2.z = 0.f;
+  o2.w = 0.f;
+}
+
+// test hook (tests/test_parity_gpu.py::test_matrix_pipe_reduction_primitive): in = h[4][64] (sub-block s, lane), c[4][64] (the lane's
+// four channel sums), mu[2]; out = the 10 record values, through the very stage-1 / stage-2 / store / record code of the kernel
+__global__ void k_debug_mx_reduce(const float* __restrict__ in, float* __restrict__ out) {
+  __shared__ float4 q[GSR_MX_SLOT_F4];
+  const int lane = threadIdx.x & 63;
+  gsr_mx_basis K;
+  gsr_mx_basis_init(lane, K);
+  if (lane < GSR_MX_SLOT_F4) q[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  gsr_f4v D1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 4; s++) D1 = GSR_MFMA4(in[s * 64 + lane], K.Bs[s], D1);
+#pragma unroll
+  for (int c = 0; c < 4; c++) D1 = GSR_MFMA4(in[(4 + c) * 64 + lane], K.Bc[c], D1);
+  gsr_mx_finish(D1, K, reinterpret_cast<char*>(q));
+  __syncthreads();
+  if (lane == 0) {
+    float4 o0, o1, o2;
+    gsr_mx_record(q[0], q[1], q[2], q[3], q[4], in[512], in[513], o0, o1, o2);
+    out[0] = o0.x; out[1] = o0.y; out[2] = o0.z; out[3] = o0.w; out[4] = o1.x; out[5] = o1.y; out[6] = o1.z; out[7] = o1.w;
+    out[8] = o2.x; out[9] = o2.y;
+  }
+}
+
+extern "C" int gsr_debug_mx_reduce(const float* in514, float* out10, void* stream) {
+  hipLaunchKernelGGL(k_debug_mx_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, in514, out10);
+  return gsr_launch_status("debug matrix-pipe reduce");
+}
+
+#ifndef BWD_MX_WAVES
+#define BWD_MX_WAVES 4
+#endif
+template <bool DEPTH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_MX_WAVES, 8))) void k_render_bwd_tile_mx(
+    int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dinvdepth,
+    const uint32_t* __restrict__ slot_of_pos, float4* __restrict__ igrad, const uint32_t* __restrict__ n_dev, uint32_t cap,
+    int prio1, int prio2, int prio3) {
+  __shared__ float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH];
+  if (gsr_overflowed(n_dev, cap)) return;
+  __shared__ float4 qbuf[BWD1_BATCH * GSR_MX_SLOT_F4];
+  const int tile = blockIdx.x;
+  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+  const int lane = threadIdx.x;
+  const uint2 range = ranges[tile];
+  const int len = (int)(range.y - range.x);
+  if (len == 0) return;
+
+  const size_t N = (size_t)W * H;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const float px0 = (float)(tile_x * GSR_TILE + (lane & 7)), py0 = (float)(tile_y * GSR_TILE + (lane >> 3));
+  float T[4], S[4], gp2[4], gd[4], nTb[4];
+  gsr_f2 gp01[4];
+  int last[4];
+  int sub_last[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int px = tile_x * GSR_TILE + (s & 1) * 8 + (lane & 7), py = tile_y * GSR_TILE + (s >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const size_t pix = (size_t)py * W + px;
+    T[s] = inside ? final_T[pix] : 0.f;
+    last[s] = inside ? (int)n_contrib[pix] : 0;
+    const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[N + pix] : 0.f;
+    gp01[s] = gsr_f2{g0, g1};
+    gp2[s] = inside ? dL_dpix[2 * N + pix] : 0.f;
+    gd[s] = (DEPTH && inside) ? dL_dinvdepth[pix] : 0.f;
+    nTb[s] = -T[s] * (bg0 * g0 + bg1 * g1 + bg2 * gp2[s]);
+    S[s] = 0.f;
+    int m = last[s];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    sub_last[s] = __builtin_amdgcn_readfirstlane(m);
+  }
+  const int toDo = min(len, max(max(sub_last[0], sub_last[1]), max(sub_last[2], sub_last[3])));
+  if (prio1 != -2) {   // issue priority for long walks (see k_render_bwd_tile)
+    int t1 = prio1, t2 = prio2, t3 = prio3;
+    if (prio1 < 0) {
+      const uint32_t sp = ((uint32_t)lane * 2654435761u + (uint32_t)tile * 40503u + 12345u) % (uint32_t)N;
+      float m = (float)n_contrib[sp];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) m += __shfl_xor(m, d, 64);
+      m *= (1.0f / 64.0f);
+      t1 = (int)(1.4f * m); t2 = (int)(1.65f * m); t3 = (int)(1.9f * m);
+    }
+    if (toDo >= t3) __builtin_amdgcn_s_setprio(3);
+    else if (toDo >= t2) __builtin_amdgcn_s_setprio(2);
+    else if (toDo >= t1) __builtin_amdgcn_s_setprio(1);
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = toDo + lane; i < len; i += 64) {   // entries behind the deepest contributor: zero records
+    float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + i];
+    dst[0] = z4; dst[1] = z4; dst[2] = z4;
+  }
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  const float4 *s0v = s0 + vzero, *s1v = s1 + vzero, *s2v = s2 + vzero;
+  gsr_mx_basis K;
+  gsr_mx_basis_init(lane, K);
+  const float cx = (float)(tile_x * GSR_TILE) + 7.5f, cy = (float)(tile_y * GSR_TILE) + 7.5f;
+  const gsr_f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+  gsr_f4v D1 = zero4;
+  gsr_f2 C01 = {0.f, 0.f}, C23 = {0.f, 0.f};
+
+  const int rounds = (toDo + BWD1_BATCH - 1) / BWD1_BATCH;
+  for (int b = 0; b < rounds; b++) {
+    __syncthreads();
+    const int e_idx = toDo - 1 - (b * BWD1_BATCH + lane);
+    uint32_t mymask = 0u;
+    if (e_idx >= 0) {
+      const uint32_t id32 = point_list[range.x + e_idx];
+      if (id32 != 0xFFFFFFFFu) {
+        const size_t id = id32;
+        const float4 r0 = rec[3 * id + 0], r1 = rec[3 * id + 1];
+        s0[lane] = r0;
+        s1[lane] = r1;
+        s2[lane] = rec[3 * id + 2];
+        mymask = gsr_subblock_mask(r0, r1, (float)(tile_x * GSR_TILE), (float)(tile_y * GSR_TILE));
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          if (e_idx + 1 > sub_last[s]) mymask &= ~(1u << s);
+      } else {
+        s0[lane] = z4;
+        s1[lane] = make_float4(0.f, 0.f, 3.0e38f, 0.f);
+        s2[lane] = z4;
+      }
+    }
+    __syncthreads();
+    const int n = min(BWD1_BATCH, toDo - b * BWD1_BATCH);
+    uint64_t done = 0ull;                               // (scalar) entries of this batch that left numbers in qbuf
+    uint64_t todo = BALLOT(mymask != 0u);
+    if (todo != 0ull) {
+      int j = (int)__builtin_ctzll(todo);
+      float4 a = s0v[j], bb = s1v[j];
+      while (true) {
+        todo &= todo - 1ull;
+        const int jn = todo != 0ull ? (int)__builtin_ctzll(todo) : j;
+        const uint32_t emask = (uint32_t)__builtin_amdgcn_readlane((int)mymask, j);
+        const int entry1 = toDo - (b * BWD1_BATCH + j);
+        bool any = false;
+        const float dx0 = a.x - px0, dy0 = a.y - py0;
+        float4 c;
+        bool have_c = false;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          if (!(emask & (1u << s))) continue;
+          const float dx = dx0 - (float)((s & 1) * 8), dy = dy0 - (float)((s >> 1) * 8);
+          const float power = gsr_power2(a, bb, dx, dy);
+          const float G = __builtin_amdgcn_exp2f(power);
+          const float alpha = fminf(0.99f, bb.y * G);
+          const bool ok = entry1 <= last[s] && power <= 0.0f && alpha >= ALPHA_MIN;
+          if ((BALLOT(entry1 <= last[s]) & BALLOT(power <= 0.0f) & BALLOT(alpha >= ALPHA_MIN)) == 0ull) continue;
+          if (!have_c) { c = s2v[j]; have_c = true; }
+          any = true;
+          const float a_e = ok ? alpha : 0.f;
+          const float G_e = ok ? G : 0.f;
+          const float rcp = __builtin_amdgcn_rcpf(1.0f - a_e);
+          T[s] = T[s] * rcp;
+          const float dch = a_e * T[s];
+          float cg = bb.w * gp01[s].x + c.x * gp01[s].y + c.y * gp2[s];
+          if (DEPTH) cg += c.z * gd[s];
+          const float diff = cg - S[s];
+          S[s] = __builtin_fmaf(a_e, diff, S[s]);
+          const float dL_dalpha = diff * T[s] + nTb[s] * rcp;
+          const float v5 = G_e * dL_dalpha;               // this pixel's dL/dopacity_eff (see k_render_bwd_tile)
+          D1 = GSR_MFMA4(v5, K.Bs[s], D1);
+          C01 = __builtin_elementwise_fma(gsr_f2{dch, dch}, gp01[s], C01);
+          C23.x = __builtin_fmaf(dch, gp2[s], C23.x);
+          if (DEPTH) C23.y = __builtin_fmaf(dch, gd[s], C23.y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a = s0v[jn];
+        bb = s1v[jn];
+        __builtin_amdgcn_sched_barrier(0);
+        if (any) {
+          D1 = GSR_MFMA4(C01.x, K.Bc[0], D1);
+          D1 = GSR_MFMA4(C01.y, K.Bc[1], D1);
+          D1 = GSR_MFMA4(C23.x, K.Bc[2], D1);
+          if (DEPTH) D1 = GSR_MFMA4(C23.y, K.Bc[3], D1);
+          gsr_mx_finish(D1, K, reinterpret_cast<char*>(qbuf) + j * (GSR_MX_SLOT_F4 * 16));
+          done |= 1ull << j;
+          D1 = zero4;
+          C01 = C23 = gsr_f2{0.f, 0.f};
+        }
+        if (todo == 0ull) break;
+        j = jn;
+      }
+    }
+    __syncthreads();
+    D1 = zero4;
+    C01 = C23 = gsr_f2{0.f, 0.f};
+    // flush the batch: lane j turns entry j's numbers into its record, at the entry's emission slot
+    if (lane < n) {
+      const int e = toDo - 1 - (b * BWD1_BATCH + lane);
+      const uint32_t slot = slot_of_pos[range.x + e];
+      float4 o0 = z4, o1 = z4, o2 = z4;
+      if ((done >> lane) & 1ull) {
+        const float4* q = qbuf + GSR_MX_SLOT_F4 * lane;
+        const float4 m = s0[lane];
+        gsr_mx_record(q[0], q[1], q[2], q[3], q[4], m.x - cx, m.y - cy, o0, o1, o2);
+      }
+      float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot;
+      dst[0] = o0; dst[1] = o1; dst[2] = o2;
+    }
+  }
+}
+
 void gsr_launch_render_fwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,
                            const uint32_t* point_list, const float4* rec, float* out_color, float* out_invdepth,
                            float* final_T, uint32_t* n_contrib, const uint32_t* status_src, uint32_t* status_dst,
@@ -1039,6 +1343,18 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
   int p1 = -1, p2 = -1, p3 = -1;
   if (const char* pr = getenv("GSR_BWD_PRIO")) {
     if (sscanf(pr, "%d,%d,%d", &p1, &p2, &p3) != 3) p1 = p2 = p3 = -2;
+  }
+  // GSR_BWD_REDUCE=swap keeps the v_permlane / DPP halving tree; the default takes the sums on the matrix pipe (k_render_bwd_tile_mx)
+  const char* red = getenv("GSR_BWD_REDUCE");
+  const bool mx = mask && !(red && !strcmp(red, "swap"));
+  if ((!quad || (form && !strcmp(form, "tile"))) && mx) {
+    if (dL_dinvdepth)
+      GSR_LAUNCH("render_bwd", (k_render_bwd_tile_mx<true>), dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height, grid_x,
+                 ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3);
+    else
+      GSR_LAUNCH("render_bwd", (k_render_bwd_tile_mx<false>), dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height, grid_x,
+                 ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3);
+    return;
   }
   if (!quad || (form && !strcmp(form, "tile"))) {
 #define GSR_BWD_TILE_LAUNCH(D, M)                                                                                          \

@@ -96,6 +96,7 @@ EXPORTS = {
     "gsr_debug_geometry_views": (C.c_int, [C.c_void_p, C.c_int32] + [C.POINTER(C.c_void_p)] * 7),
     "gsr_debug_wave_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_wave_reduce_pk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_debug_mx_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_binning_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p)]),
     "gsr_debug_count_pairs": (C.c_int, [C.POINTER(gsr_settings), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -138,7 +139,7 @@ EXPORTS = {
 }
 
 ADAM_DYNAMIC_FLOATS = 18     # GSR_ADAM_DYNAMIC_FLOATS
-ABI_VERSION = 6      # GSR_ABI_VERSION of include/gsr.h
+ABI_VERSION = 7      # GSR_ABI_VERSION of include/gsr.h
 _lib = None
 
 

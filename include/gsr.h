@@ -31,11 +31,12 @@
 extern "C" {
 #endif
 
-/* 6: host_status word 0 bit 0 = radix-sort look-back time-out (was reserved; debug = 1 fails the call), gsr_debug_wave_reduce_pk,
+/* 7: gsr_debug_mx_reduce (the compositing backward's sums on the matrix pipe; GSR_BWD_REDUCE=swap keeps the round-3/4 tree);
+ * 6: host_status word 0 bit 0 = radix-sort look-back time-out (was reserved; debug = 1 fails the call), gsr_debug_wave_reduce_pk,
  *    gsr_forward_async_culled (host_status word 0 bit 1 / word 6 = a truncated tile list was too short);
  * 5: gsr_fused_adam.dynamic + gsr_adam_set_dynamic (optimizer factors in device memory, for HIP-graph replay), gsr_l1_mean_*;
  * 4: gsr_forward_async(num_rendered_out) / gsr_forward_rerender (verified speculation), gsr_sh_rank1_*; 3: gsr_backward_adam */
-#define GSR_ABI_VERSION 6
+#define GSR_ABI_VERSION 7
 
 enum {
   GSR_OK = 0,
@@ -285,6 +286,11 @@ int gsr_debug_geometry_views(const void* geometry_state, int32_t P, const float*
 int gsr_debug_wave_reduce(const float* in640, float* out20, void* stream);
 /* the same sums through the packed-pair trees (v_pk_add_f32 behind the swap stages) of k_render_bwd_tile; same layout */
 int gsr_debug_wave_reduce_pk(const float* in640, float* out20, void* stream);
+/* test hook: the matrix-pipe form of the same reduction (k_render_bwd_tile_mx: v_mfma_f32_16x16x4_f32 against the tile's pixel basis).
+ * in[514] = h[4][64] (sub-block s = 0..3, lane: the pixel's dL/dopacity_eff), c[4][64] (the lane's channel sums), mu[2] (the 2-D mean
+ * relative to the tile centre); out[10] = the gradient record's ten values (sum h dx, sum h dy, sum h dx^2, sum h dx dy, sum h dy^2,
+ * sum h, c0..c3) with d = mu - pixel, pixel (x, y) of (s, lane) = ((lane & 7) + 8 (s & 1) - 7.5, (lane >> 3) + 8 (s >> 1) - 7.5) */
+int gsr_debug_mx_reduce(const float* in514, float* out10, void* stream);
 int gsr_debug_binning_views(const void* binning_state, int32_t image_width, int32_t image_height,
                             int64_t num_rendered, const uint32_t** point_list, const uint32_t** ranges);
 /* Pair evaluations of the compositing forward (SURVEY.md 8(d) "FLOP model"): pairs[2*H*W] (uint32) = per pixel, the number of

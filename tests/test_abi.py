@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_size_queries():
     from diff_gaussian_rasterization import _C
     lib = _C.lib()
-    assert lib.gsr_abi_version() == _C.ABI_VERSION == 6
+    assert lib.gsr_abi_version() == _C.ABI_VERSION == 7
     g1, g2 = lib.gsr_geometry_state_bytes(1000), lib.gsr_geometry_state_bytes(2000)
     assert 0 < g1 < g2 and g1 % 256 == 0
     assert lib.gsr_image_state_bytes(1920, 1080) >= 1920 * 1080 * 8

@@ -202,13 +202,16 @@ def test_backward_subblock_masks_change_no_bit(depth, aa, aniso):
     cam = fibonacci_cameras(3, 208, 144, seed=403)[2]
     bg = torch.tensor([0.3, 0.2, 0.1])
     gc, gd = upstream_grads(cam.image_height, cam.image_width, depth=depth)
-    old = {k: os.environ.get(k) for k in ("GSR_BWD_FORM", "GSR_BWD_MASK")}
+    old = {k: os.environ.get(k) for k in ("GSR_BWD_FORM", "GSR_BWD_MASK", "GSR_BWD_REDUCE")}
     try:
         os.environ["GSR_BWD_FORM"] = "tile"
+        os.environ["GSR_BWD_REDUCE"] = "swap"       # (the halving-tree form of the masked kernel: the one that shares its tree with round 3)
         os.environ["GSR_BWD_MASK"] = "0"
         a = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
         os.environ["GSR_BWD_MASK"] = "1"
         b = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
+        os.environ.pop("GSR_BWD_REDUCE")            # the default: the same masked walk, sums on the matrix pipe (k_render_bwd_tile_mx)
+        m = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
     finally:
         for k, v in old.items():
             if v is None:
@@ -219,10 +222,23 @@ def test_backward_subblock_masks_change_no_bit(depth, aa, aniso):
     for k in a["grads"]:
         assert torch.equal(a["grads"][k], b["grads"][k]), (k, float((a["grads"][k] - b["grads"][k]).abs().max()))
     assert float(b["grads"]["means3D"].abs().sum()) > 0
+    # the matrix-pipe form adds the same terms in another (fixed) order: equal to fp32 rounding, not bit for bit
+    ref = run_oracle(raw, cam, 2, bg, torch.float64, antialiasing=aa, gc=gc, gd=gd)     # (depth=False: gd is all zeros)
+    for k in b["grads"]:
+        gb, gm, gr = b["grads"][k].double().cpu(), m["grads"][k].double().cpu(), ref["grads"][k].double()
+        if not aniso:
+            assert float((gb - gm).norm()) <= 2e-6 * float(gb.norm()) + 1e-30, (k, float((gb - gm).norm() / gb.norm()))
+            assert float((gb - gm).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-30, (k, float((gb - gm).abs().max()))
+        else:
+            # needles: float32 itself is 1e-3 .. 1e-2 away from float64 on this scene (ill-conditioned conics; measured for both
+            # forms, tests/sweeps/mx_vs_swap_error.py), so the two orders of summation differ by that much from each other; what
+            # is asked of the matrix-pipe form is that it is no farther from float64 than the tree
+            eb, em = float((gb - gr).norm() / gr.norm()), float((gm - gr).norm() / gr.norm())
+            assert em <= 1.5 * eb + 2e-6, (k, em, eb)
     if not aniso:      # (the needle scene is there for the masks; its conics are too ill-conditioned for the 2e-5 image bar)
-        ref = run_oracle(raw, cam, 2, bg, torch.float64, antialiasing=aa, gc=gc, gd=gd)     # (depth=False: gd is all zeros)
         check_forward(b, ref)
         check_grads(b, ref)
+        check_grads(m, ref)
 
 
 @pytest.mark.parametrize("aa,aniso,P,scale", [(False, 0.0, 6000, 0.8), (True, 1.3, 6000, 0.8), (False, 0.0, 20000, 2.5)])
@@ -443,6 +459,37 @@ def test_wave_reduction_primitive():
     _C.check(lib.gsr_debug_wave_reduce_pk(_C.ptr(x), _C.ptr(o2), _C._stream()))
     torch.cuda.synchronize()
     assert torch.equal(o1, o2)
+
+
+def test_matrix_pipe_reduction_primitive():
+    """Round 4: k_render_bwd_tile_mx takes an entry's ten sums over the tile's 256 pixels on the matrix pipe (v_mfma_f32_16x16x4_f32
+    against the tile's separable pixel basis, csrc/render.hip).  The hook runs that very stage-1 / stage-2 / LDS slot / record code
+    on h[4][64], c[4][64] and a mean; with small integer h and half-integer means every product and partial sum is exact in float32,
+    so a wrong lane map, basis entry or slot offset shows as a wrong number (asymmetric random data: no row <-> column swap can hide)."""
+    import numpy as np
+    from diff_gaussian_rasterization import _C
+    lib = _C.lib()
+    rng = np.random.default_rng(7)
+    lane = np.arange(64)
+    for trial in range(6):
+        h = rng.integers(-8, 9, size=(4, 64)).astype(np.float64)
+        c = rng.integers(-100, 101, size=(4, 64)).astype(np.float64)
+        if trial == 0:                      # one pixel only: the basis values themselves
+            h[:] = 0
+            h[3, 37] = 1.0
+        if trial == 1:                      # one sub-block only
+            h[[0, 1, 3]] = 0
+        mu = rng.integers(-20, 21, size=2) * 0.5
+        X = np.stack([(lane & 7) + 8 * (s & 1) - 7.5 for s in range(4)])
+        Y = np.stack([(lane >> 3) + 8 * (s >> 1) - 7.5 for s in range(4)])
+        dx, dy = mu[0] - X, mu[1] - Y
+        want = np.array([(h * dx).sum(), (h * dy).sum(), (h * dx * dx).sum(), (h * dx * dy).sum(), (h * dy * dy).sum(), h.sum(),
+                         c[0].sum(), c[1].sum(), c[2].sum(), c[3].sum()])
+        xin = torch.from_numpy(np.concatenate([h.ravel(), c.ravel(), mu]).astype(np.float32)).cuda().contiguous()
+        out = torch.zeros(10, device="cuda")
+        _C.check(lib.gsr_debug_mx_reduce(_C.ptr(xin), _C.ptr(out), _C._stream()))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().astype(np.float64), want), (trial, out.cpu().numpy(), want)
 
 
 def test_config4_code_path_small():
