@@ -1020,6 +1020,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
 // Every sum is still taken in a fixed order (bitwise reproducible); it is a DIFFERENT order than the swap tree's, so this form agrees
 // with the other two to rounding, not bit for bit (tests: parity against the float64 oracle at the same bar, and the basis / lane maps
 // against exact integer data, tests/test_parity_gpu.py::test_matrix_pipe_reduction_primitive).
+//
+// MEASURED OUT (opt-in, GSR_BWD_REDUCE=mfma): 27 % fewer vector instructions per launch (1.88e8 -> 1.38e8 + 1.38e7 MFMAs) and
+// 0.52 ms against the tree's 0.42 at C3.  The premise was wrong for THIS data type: on gfx950 an FP32-input MFMA executes on the
+// vector FP32 datapath - SQ_VALU_MFMA_COEXEC_CYCLES = 0 for the launch, and tools/mfma_coexec_microbench.hip shows a v_fma_f32
+// wave taking exactly its own time PLUS the 32 cycles of every v_mfma_f32_16x16x4_f32 a second wave of its SIMD issues (a bf16
+// MFMA costs it ~6) - so each of the ~8.3 MFMAs per entry is worth eight plain instructions, more than the tree it replaces.  A
+// bf16 form would need every f32 value split in three (5-6 instructions each): no gain left.  Kept as evidence and for its tests.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float gsr_f4v __attribute__((ext_vector_type(4)));
 #define GSR_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -1344,9 +1351,10 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
   if (const char* pr = getenv("GSR_BWD_PRIO")) {
     if (sscanf(pr, "%d,%d,%d", &p1, &p2, &p3) != 3) p1 = p2 = p3 = -2;
   }
-  // GSR_BWD_REDUCE=swap keeps the v_permlane / DPP halving tree; the default takes the sums on the matrix pipe (k_render_bwd_tile_mx)
+  // GSR_BWD_REDUCE=mfma (opt-in, measured SLOWER: 0.52 against 0.42 ms at C3, profiles/r04_bwd_mx_ab.txt) takes the sums with
+  // v_mfma_f32_16x16x4_f32 (k_render_bwd_tile_mx); the default is the v_permlane / DPP halving tree
   const char* red = getenv("GSR_BWD_REDUCE");
-  const bool mx = mask && !(red && !strcmp(red, "swap"));
+  const bool mx = mask && red && !strcmp(red, "mfma");
   if ((!quad || (form && !strcmp(form, "tile"))) && mx) {
     if (dL_dinvdepth)
       GSR_LAUNCH("render_bwd", (k_render_bwd_tile_mx<true>), dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height, grid_x,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-/* 7: gsr_debug_mx_reduce (the compositing backward's sums on the matrix pipe; GSR_BWD_REDUCE=swap keeps the round-3/4 tree);
+/* 7: gsr_debug_mx_reduce (the compositing backward's sums on the matrix pipe: opt-in form GSR_BWD_REDUCE=mfma, measured slower);
  * 6: host_status word 0 bit 0 = radix-sort look-back time-out (was reserved; debug = 1 fails the call), gsr_debug_wave_reduce_pk,
  *    gsr_forward_async_culled (host_status word 0 bit 1 / word 6 = a truncated tile list was too short);
  * 5: gsr_fused_adam.dynamic + gsr_adam_set_dynamic (optimizer factors in device memory, for HIP-graph replay), gsr_l1_mean_*;

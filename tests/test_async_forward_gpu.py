@@ -434,8 +434,8 @@ def test_lowlevel_forward_ignores_state_contents_and_reports_prefiltered_culls(t
 def test_parity_suite_with_the_other_backward_form_and_other_forward_modes():
     """The two forms of the compositing backward (one wave per tile from 6000 tiles up, four waves per tile below) are chosen by
     image size, so the small-image parity tests only ever see the four-wave form.  Re-run the core parity tests in a child
-    process with GSR_BWD_FORM=tile (its default reduction: the matrix pipe, k_render_bwd_tile_mx; a second child keeps the
-    v_permlane / DPP tree, GSR_BWD_REDUCE=swap) and the unverified forward (GSR_FORWARD_MODE=async; two parity modes, edge cases,
+    process with GSR_BWD_FORM=tile (a second child takes its opt-in matrix-pipe reduction, GSR_BWD_REDUCE=mfma:
+    k_render_bwd_tile_mx) and the unverified forward (GSR_FORWARD_MODE=async; two parity modes, edge cases,
     bitwise repeat, committed golden), and once more with the blocking forward (GSR_FORWARD_MODE=sync), the global binning form and the
     colour pass on the side stream."""
     import os
@@ -448,7 +448,7 @@ def test_parity_suite_with_the_other_backward_form_and_other_forward_modes():
     sel = [par + "[sh-True-False]", par + "[colors-True-True]", "tests/test_parity_gpu.py::test_edge_cases",
            "tests/test_parity_gpu.py::test_bitwise_reproducible", "tests/test_parity_gpu.py::test_against_committed_golden"]
     for extra, tests in (({"GSR_BWD_FORM": "tile", "GSR_FORWARD_MODE": "async"}, sel),
-                         ({"GSR_BWD_FORM": "tile", "GSR_BWD_REDUCE": "swap"}, sel[0:3]),     # (the halving-tree form of that kernel)
+                         ({"GSR_BWD_FORM": "tile", "GSR_BWD_REDUCE": "mfma"}, sel[0:3]),     # (the opt-in matrix-pipe form of that kernel)
                          ({"GSR_BWD_FORM": "quad", "GSR_FORWARD_MODE": "sync", "GSR_SHADE_STREAM": "1"}, sel[1:4]),
                          ({"GSR_BINNING": "global", "GSR_SHADE_STREAM": "1"}, sel[2:4])):
         env = dict(os.environ, **extra)

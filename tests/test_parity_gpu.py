@@ -205,12 +205,12 @@ def test_backward_subblock_masks_change_no_bit(depth, aa, aniso):
     old = {k: os.environ.get(k) for k in ("GSR_BWD_FORM", "GSR_BWD_MASK", "GSR_BWD_REDUCE")}
     try:
         os.environ["GSR_BWD_FORM"] = "tile"
-        os.environ["GSR_BWD_REDUCE"] = "swap"       # (the halving-tree form of the masked kernel: the one that shares its tree with round 3)
+        os.environ["GSR_BWD_REDUCE"] = "swap"       # (the default: the halving-tree form, which shares its tree with round 3)
         os.environ["GSR_BWD_MASK"] = "0"
         a = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
         os.environ["GSR_BWD_MASK"] = "1"
         b = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
-        os.environ.pop("GSR_BWD_REDUCE")            # the default: the same masked walk, sums on the matrix pipe (k_render_bwd_tile_mx)
+        os.environ["GSR_BWD_REDUCE"] = "mfma"       # opt-in form: the same masked walk, sums on the matrix pipe (k_render_bwd_tile_mx)
         m = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
     finally:
         for k, v in old.items():
@@ -462,7 +462,7 @@ def test_wave_reduction_primitive():
 
 
 def test_matrix_pipe_reduction_primitive():
-    """Round 4: k_render_bwd_tile_mx takes an entry's ten sums over the tile's 256 pixels on the matrix pipe (v_mfma_f32_16x16x4_f32
+    """Round 4 (opt-in form, GSR_BWD_REDUCE=mfma; measured slower, kept as evidence): k_render_bwd_tile_mx takes an entry's ten sums over the tile's 256 pixels on the matrix pipe (v_mfma_f32_16x16x4_f32
     against the tile's separable pixel basis, csrc/render.hip).  The hook runs that very stage-1 / stage-2 / LDS slot / record code
     on h[4][64], c[4][64] and a mean; with small integer h and half-integer means every product and partial sum is exact in float32,
     so a wrong lane map, basis entry or slot offset shows as a wrong number (asymmetric random data: no row <-> column swap can hide)."""

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the compositing backward's reduction: matrix pipe (default, k_render_bwd_tile_mx) against the v_permlane / DPP tree
+# A/B of the compositing backward's reduction: matrix pipe (opt-in, k_render_bwd_tile_mx) against the default v_permlane / DPP tree
 # (GSR_BWD_REDUCE=swap); driver command, interleaved twice.  AB_CONFIG=N / AB_EXTRA="--scale-factor 2" pick another workload.
 show() { python3 -c "
 import json,sys;d=json.loads(open('gpurun_out/ab.json').read()); k=d['kernels']
