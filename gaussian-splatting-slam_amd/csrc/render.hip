@@ -145,6 +145,9 @@ __device__ __forceinline__ void wave_sum9_halving_pk(gsr_f2 P0, gsr_f2 P1, gsr_f
   b += dpp_get<0x140>(b);
   b += dpp_get<0x142>(b);
   b += dpp_get<0x143>(b);
+  // (the totals are formed HERE: left to itself the compiler sinks the last add of each chain into the caller's lane-predicated
+  // store block and pays a v_mov_b32_dpp + v_add_f32 for what is one v_add_f32_dpp)
+  asm volatile("" : "+v"(a), "+v"(b));
   u0 = a;
   u1 = b;
 }
@@ -745,6 +748,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
   const int u1_slot = DEPTH ? 8 + (lane >> 5) : 8;
   const int octet_val = (((lane >> 3) & 1) << 2) | ((lane >> 3) & 2) | (((lane >> 3) & 4) >> 2);
   const int octet_val_pk = GSR_OCTET_VALUE_PK(lane >> 3);   // (packed-pair trees: another value order over the octets)
+  // (nine-value form: the lane holding the ninth total, 63, leads no octet - one per-lane slot offset serves both stores of a record)
+  float* const st_pk = reinterpret_cast<float*>(outb) + (octet_lead ? octet_val_pk : 8);
   const int octet_val_lds = (((lane >> 3) & 1) << 2) | (lane >> 4);   // (LDS form: row q holds values q | 4 + q)
   (void)octet_val_pk; (void)octet_val_lds;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f, acc5 = 0.f, acc6 = 0.f, acc7 = 0.f, acc8 = 0.f,
@@ -925,10 +930,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
         pend_j = j;
         (void)u0; (void)u1; (void)dst;
 #else
-        if (DEPTH) wave_sum10_halving_pk(A01, A23, A45, A67, A89, lane_bit3, u0, u1);
-        else wave_sum9_halving_pk(A01, A23, A45, A67, A89.x, lane_bit3, u0, u1);
-        if (octet_lead) dst[octet_val_pk] = u0;
-        if (u1_lead) dst[u1_slot] = u1;
+        if (DEPTH) {
+          wave_sum10_halving_pk(A01, A23, A45, A67, A89, lane_bit3, u0, u1);
+          if (octet_lead) dst[octet_val_pk] = u0;
+          if (u1_lead) dst[u1_slot] = u1;
+        } else {
+          wave_sum9_halving_pk(A01, A23, A45, A67, A89.x, lane_bit3, u0, u1);
+          if (octet_lead) st_pk[12 * j] = u0;
+          if (u1_lead) st_pk[12 * j] = u1;
+        }
 #endif
         A01 = A23 = A45 = A67 = A89 = gsr_f2{0.f, 0.f};
         return;
