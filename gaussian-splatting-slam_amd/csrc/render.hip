@@ -77,6 +77,7 @@ __device__ __forceinline__ void wave_sum10_halving(float v0, float v1, float v2,
   b += dpp_get<0x4E>(b);
   a += dpp_get<0x141>(a);                  // row_half_mirror
   b += dpp_get<0x141>(b);
+  asm volatile("" : "+v"(a), "+v"(b));     // (totals formed here, not sunk into the caller's lane-predicated store blocks)
   u0 = a;
   u1 = b;
 }
@@ -101,6 +102,7 @@ __device__ __forceinline__ void wave_sum9_halving(float v0, float v1, float v2, 
   b += dpp_get<0x140>(b);                  // row_mirror
   b += dpp_get<0x142>(b);                  // row_bcast:15: row k += row k-1  (row 3 = r3 + r2, row 1 = r1 + r0)
   b += dpp_get<0x143>(b);                  // row_bcast:31: row 3 += lane 31 = r1 + r0   (rows 0..2: don't care)
+  asm volatile("" : "+v"(a), "+v"(b));     // (see wave_sum10_halving)
   u0 = a;
   u1 = b;
 }
@@ -168,6 +170,7 @@ __device__ __forceinline__ void wave_sum10_halving_pk(gsr_f2 P0, gsr_f2 P1, gsr_
   b += dpp_get<0x4E>(b);
   a += dpp_get<0x141>(a);
   b += dpp_get<0x141>(b);
+  asm volatile("" : "+v"(a), "+v"(b));   // (totals formed here, not sunk into the caller's store blocks: see the nine-value tree)
   u0 = a;
   u1 = b;
 }
@@ -669,7 +672,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
                                                         const uint32_t* __restrict__ slot_of_pos,
                                                         float4* __restrict__ igrad, const uint32_t* __restrict__ n_dev,
                                                         uint32_t cap, int prio1, int prio2, int prio3) {
-  __shared__ float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH];   // +2: the prefetch may touch [n+1]
+  // (one object: the three arrays sit at fixed distances, so an entry's reads share ONE address register and differ in the
+  // instruction's immediate offset - two v_add_u32 per walked entry less than three separate __shared__ arrays cost)
+  __shared__ struct { float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH]; } stg;   // +2: the prefetch may touch [n+1]
+  float4 (&s0)[BWD1_BATCH + 2] = stg.s0;
+  float4 (&s1)[BWD1_BATCH + 2] = stg.s1;
+  float4 (&s2)[BWD1_BATCH] = stg.s2;
   if (gsr_overflowed(n_dev, cap)) return;   // grid-uniform: a truncated frame teaches nothing (gsr_common.h)
   __shared__ float4 outb[BWD1_BATCH * GSR_IGRAD_F4];                          // the batch's gradient records
 #if BWD_LDS_REDUCE
@@ -742,7 +750,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
   }
   int vzero;   // keeps the LDS base in a VGPR (see k_render_bwd)
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  const float4 *s0v = s0 + vzero, *s1v = s1 + vzero, *s2v = s2 + vzero;
+  const char* const stgv = reinterpret_cast<const char*>(&stg) + vzero;
+  const float4* const s0v = reinterpret_cast<const float4*>(stgv);
+  const float4* const s1v = reinterpret_cast<const float4*>(stgv + sizeof(stg.s0));
+  const float4* const s2v = reinterpret_cast<const float4*>(stgv + sizeof(stg.s0) + sizeof(stg.s1));
   const bool lane_bit3 = (lane & 8) != 0, octet_lead = (lane & 7) == 0;
   const bool u1_lead = DEPTH ? (lane & 31) == 0 : lane == 63;
   const int u1_slot = DEPTH ? 8 + (lane >> 5) : 8;
