@@ -27,17 +27,17 @@ void gsr_launch_mark_visible(int, const float*, const float*, uint8_t*, hipStrea
 void gsr_launch_emit(int, int, int, char*, const GsrGeomLayout&, char*, const GsrBinLayout&, uint32_t, bool, unsigned long long*,
                      int, const uint32_t*, hipStream_t);
 void gsr_launch_tile_depth_sort(int, bool, uint2*, const uint2*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*,
-                                uint32_t*, uint32_t*, hipStream_t);
+                                uint32_t*, uint32_t*, uint32_t*, hipStream_t);
 void gsr_launch_finalize(uint32_t, const uint32_t*, const uint32_t*, char*, const GsrBinLayout&, hipStream_t);
 void gsr_launch_sum_tiles(int, const char*, const GsrGeomLayout&, uint32_t*, hipStream_t);
 void gsr_launch_render_fwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, float*,
                            float*, float*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,
-                           uint32_t, uint32_t*, hipStream_t);
+                           uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, hipStream_t);
 void gsr_launch_count_pairs(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*, uint32_t*,
                             hipStream_t);
 void gsr_launch_render_bwd(const gsr_settings*, int, int, const uint2*, const uint32_t*, const float4*,
                            const float*, const uint32_t*, const float*, const float*, const uint32_t*, float4*,
-                           const uint32_t*, uint32_t, hipStream_t);
+                           const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------
 // errors
@@ -252,7 +252,7 @@ int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 const char* gsr_last_error(void) { return t_err; }
 
 size_t gsr_geometry_state_bytes(int32_t P) { return gsr_geom_layout((size_t)(P < 0 ? 0 : P)).total; }
-size_t gsr_image_state_bytes(int32_t W, int32_t H) { return gsr_img_layout((size_t)W * (size_t)H).total; }
+size_t gsr_image_state_bytes(int32_t W, int32_t H) { return gsr_img_layout(W, H).total; }
 size_t gsr_binning_state_bytes(int32_t P, int32_t W, int32_t H, int64_t R) {
   (void)P;
   const size_t tiles = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * (size_t)((H + GSR_TILE - 1) / GSR_TILE);
@@ -486,7 +486,7 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   const size_t R = (size_t)num_rendered;
   const GsrGeomLayout GL = gsr_geom_layout(g->P);
   const GsrBinLayout BL = gsr_bin_layout(R, tiles);
-  const GsrImgLayout IL = gsr_img_layout((size_t)W * H);
+  const GsrImgLayout IL = gsr_img_layout(W, H);
   if (!binning_state || binning_bytes < BL.total || !image_state || image_bytes < IL.total) {
     gsr_set_error("binning/image state too small: %zu < %zu or %zu < %zu", binning_bytes, BL.total, image_bytes,
                   IL.total);
@@ -496,6 +496,11 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
   char* bin = (char*)binning_state;
   char* img = (char*)image_state;
   const uint32_t* n_dev = g->P > 0 ? (const uint32_t*)(geom + GL.meta) + 2 : nullptr;
+  // (round 4) walk classes: with a backward to follow, the compositing kernel files every tile under the class of its walk length
+  // (image state), and the backward takes the classes longest first.  The 64 counters are cleared by the first workgroup of the
+  // kernel in front of the compositing (tile-local form: the per-tile ordering), by a memset where there is none.
+  uint32_t* walk_cnt = for_backward ? (uint32_t*)(img + IL.walk_cnt) : nullptr;
+  bool walk_cnt_clear = false;
   if (R == 0 || g->P == 0) {   // nothing to emit: every tile range is empty (otherwise the emit kernel clears them on its way)
     if ((rc = gsr_check(hipMemsetAsync(bin + BL.ranges, 0, (size_t)tiles * 8, st), "memset ranges"))) return rc;
   } else {
@@ -559,10 +564,14 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
                                  fused_bins ? (const uint2*)(bin + BL.ranges_enc) : nullptr,
                                  (uint32_t*)(bin + point_list_offset(BL, tiles)), slots,
                                  (const uint32_t*)(geom + GL.depth_key), free_k, free_v, free_w,
-                                 (uint32_t*)(geom + GL.meta), st);
+                                 (uint32_t*)(geom + GL.meta), walk_cnt, st);
+      walk_cnt_clear = true;
       if ((rc = debug_sync(s, st, "tile depth sort"))) return rc;
     }
   }
+  if (walk_cnt && !walk_cnt_clear &&
+      (rc = gsr_check(hipMemsetAsync(walk_cnt, 0, GSR_WALK_CLASSES * 4, st), "memset walk classes")))
+    return rc;
   // status words of the non-blocking forward: written by the compositing kernel itself when the caller's slot is pinned
   // host memory (it is mapped into the device's address space), copied otherwise
   uint32_t* status_dev = (host_status_late && g->P > 0) ? device_alias_of_pinned(host_status_late) : nullptr;
@@ -583,7 +592,9 @@ static int forward_render_impl(const gsr_settings* s, const gsr_gaussians* g, vo
                         (const float4*)(geom + GL.rec), out_color, out_invdepth, (float*)(img + IL.final_T),
                         (uint32_t*)(img + IL.n_contrib), status_dev ? (const uint32_t*)(geom + GL.meta) : nullptr, status_dev,
                         (g->P > 0 && R > 0) ? tile_cutoff : nullptr, (const uint32_t*)(geom + GL.depth_key),
-                        cull_applied ? (const uint32_t*)(bin + BL.culled_any) : nullptr, frame_tag, (uint32_t*)(geom + GL.meta), st);
+                        cull_applied ? (const uint32_t*)(bin + BL.culled_any) : nullptr, frame_tag, (uint32_t*)(geom + GL.meta),
+                        walk_cnt, walk_cnt ? (uint32_t*)(img + IL.walk_list) : nullptr,
+                        walk_cnt ? (uint32_t*)(img + IL.walk_of_tile) : nullptr, st);
   if ((rc = debug_sync(s, st, "render forward"))) return rc;
   return gsr_launch_status("forward");
 }
@@ -780,7 +791,7 @@ static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const in
   }
   const GsrGeomLayout GL = gsr_geom_layout(g->P);
   const GsrBinLayout BL = gsr_bin_layout(R, tiles);
-  const GsrImgLayout IL = gsr_img_layout((size_t)W * H);
+  const GsrImgLayout IL = gsr_img_layout(W, H);
   const char* geom = (const char*)geometry_state;
   const char* bin = (const char*)binning_state;
   const char* img = (const char*)image_state;
@@ -790,7 +801,8 @@ static int backward_impl(const gsr_settings* s, const gsr_gaussians* g, const in
                           (const float4*)(geom + GL.rec), (const float*)(img + IL.final_T),
                           (const uint32_t*)(img + IL.n_contrib), dL_dcolor, dL_dinvdepth,
                           (const uint32_t*)(bin + (tile_sort_result_buffer(tiles) ? BL.val_b : BL.val_a)), igrad,
-                          (const uint32_t*)(geom + GL.meta) + 2, (uint32_t)R, st);
+                          (const uint32_t*)(geom + GL.meta) + 2, (uint32_t)R, (const uint32_t*)(img + IL.walk_cnt),
+                          (const uint32_t*)(img + IL.walk_list), (const uint32_t*)(img + IL.walk_of_tile), st);
     if ((rc = debug_sync(s, st, "render backward"))) return rc;
   }
   GsrAdamArgs A;
@@ -912,11 +924,21 @@ int gsr_debug_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
 
 int gsr_debug_image_views(const void* image_state, int32_t W, int32_t H, const float** final_T,
                           const uint32_t** n_contrib) {
-  const GsrImgLayout IL = gsr_img_layout((size_t)W * H);
+  const GsrImgLayout IL = gsr_img_layout(W, H);
   const char* img = (const char*)image_state;
   if (final_T) *final_T = (const float*)(img + IL.final_T);
   if (n_contrib) *n_contrib = (const uint32_t*)(img + IL.n_contrib);
   return 0;
+}
+
+int gsr_debug_walk_views(const void* image_state, int32_t W, int32_t H, const uint32_t** walk_cnt, const uint32_t** walk_list,
+                         const uint32_t** walk_of_tile) {
+  const GsrImgLayout IL = gsr_img_layout(W, H);
+  const char* img = (const char*)image_state;
+  if (walk_cnt) *walk_cnt = (const uint32_t*)(img + IL.walk_cnt);
+  if (walk_list) *walk_list = (const uint32_t*)(img + IL.walk_list);
+  if (walk_of_tile) *walk_of_tile = (const uint32_t*)(img + IL.walk_of_tile);
+  return GSR_WALK_CLASSES;
 }
 
 void gsr_profile_enable(int32_t on) { g_gsr_profile_on = on ? 1 : 0; }

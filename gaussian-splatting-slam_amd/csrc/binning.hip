@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256) void k_tile_depth_sort(const uint2* __restrict
                                                          uint32_t* __restrict__ slot_of_pos,
                                                          const uint32_t* __restrict__ depth_key, uint32_t* __restrict__ free_a,
                                                          uint32_t* __restrict__ free_b, uint32_t* __restrict__ free_c,
-                                                         uint32_t* __restrict__ meta) {
+                                                         uint32_t* __restrict__ meta, uint32_t* __restrict__ walk_cnt) {
+  // (the walk-class counters the compositing kernel behind this launch adds to: cleared here, gsr_common.h gsr_walk_class)
+  if (walk_cnt && blockIdx.x == 0 && threadIdx.x < GSR_WALK_CLASSES) walk_cnt[threadIdx.x] = 0u;
   // LDS path: stable LSD radix sort of the list's 32-bit depth keys (8-bit digits, passes whose digit is the same for every
   // key are skipped - the keys of one tile usually differ in their low ~20 bits only), ranked like the global sort: each
   // wave ranks a contiguous quarter of the list with ballots and wave-private counters.  The position in the id-ordered
@@ -437,11 +439,12 @@ __global__ __launch_bounds__(256) void k_tile_depth_sort(const uint2* __restrict
 // the first launch decodes into `ranges`
 void gsr_launch_tile_depth_sort(int tiles, bool dual, uint2* ranges, const uint2* ranges_enc, uint32_t* point_list,
                                 uint32_t* slot_of_pos, const uint32_t* depth_key, uint32_t* free_a, uint32_t* free_b,
-                                uint32_t* free_c, uint32_t* meta, hipStream_t st) {
+                                uint32_t* free_c, uint32_t* meta, uint32_t* walk_cnt, hipStream_t st) {
   const uint2* rin = ranges_enc ? ranges_enc : (const uint2*)ranges;
+  // (ABOVEV == 0: the first launch over the tiles - the one that clears the walk-class counters)
 #define GSR_TLO(NAME, D, CAPV, ABOVEV, DEC, RIN)                                                                         \
   GSR_LAUNCH(NAME, (k_tile_depth_sort<D, CAPV, ABOVEV, DEC>), dim3(tiles), dim3(256), 0, st, RIN, ranges, point_list, \
-             slot_of_pos, depth_key, free_a, free_b, free_c, meta)
+             slot_of_pos, depth_key, free_a, free_b, free_c, meta, (ABOVEV) == 0 ? walk_cnt : (uint32_t*)nullptr)
 #if GSR_TLO_SPLIT
   if (dual) {
     if (ranges_enc) GSR_TLO("tile_depth_sort", true, GSR_TLO_SMALL, 0, true, rin);

@@ -62,9 +62,16 @@ struct GsrBinLayout {
   size_t total;
 };
 
+#define GSR_WALK_CLASSES 64
+#ifndef GSR_WALK_SUB
+#define GSR_WALK_SUB 2              // mantissa bits of a walk class: 2^SUB classes per octave of the walk length (measured: 2 classes
+#endif                              // per octave 0.396 ms at C3, 4 per octave 0.381 = what a full sort reaches, profiles/r04_bwd_lpt_ab.txt)
 struct GsrImgLayout {
   size_t final_T;        // f32[N]
   size_t n_contrib;      // u32[N]
+  size_t walk_cnt;       // u32[GSR_WALK_CLASSES]: tiles per walk class of this frame (k_render_fwd; cleared by the kernel in front of it)
+  size_t walk_list;      // u32[GSR_WALK_CLASSES][tiles]: the tiles of every class, in the order their forward workgroups finished
+  size_t walk_of_tile;   // u32[tiles]: the walk length itself (entries behind it get zero records from the workgroup of the tile's INDEX)
   size_t total;
 };
 
@@ -167,13 +174,32 @@ static inline GsrBinLayout gsr_bin_layout(size_t R, size_t tiles) {
   return L;
 }
 
-static inline GsrImgLayout gsr_img_layout(size_t N) {
+static inline GsrImgLayout gsr_img_layout(int W, int H) {
   GsrImgLayout L;
+  const size_t N = (size_t)W * (size_t)H;
+  const size_t tiles = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * (size_t)((H + GSR_TILE - 1) / GSR_TILE);
   size_t o = 0;
   L.final_T = o;   o += gsr_align(N * 4);
   L.n_contrib = o; o += gsr_align(N * 4);
+  L.walk_cnt = o;  o += gsr_align(GSR_WALK_CLASSES * 4);
+  L.walk_list = o; o += gsr_align(GSR_WALK_CLASSES * tiles * 4);
+  L.walk_of_tile = o; o += gsr_align(tiles * 4);
   L.total = o;
   return L;
+}
+// Walk class of a tile (round 4): a coarse logarithm of the number of list entries its backward walks (the deepest contributor of
+// any of its pixels) - exponent and GSR_WALK_SUB leading mantissa bits.  k_render_bwd_tile takes the tiles class by class, longest
+// walks first; inside a class the tiles keep (roughly) their natural order, which is what keeps neighbouring tiles' record gathers
+// in the same L2.
+__host__ __device__ static inline int gsr_walk_class(uint32_t w) {
+  if (GSR_WALK_SUB == 2 && w > 65535u) w = 65535u;
+  if (w < (1u << GSR_WALK_SUB)) return (int)w;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int e = 31 - __clz((int)w);
+#else
+  const int e = 31 - __builtin_clz(w);
+#endif
+  return (e << GSR_WALK_SUB) + (int)((w >> (e - GSR_WALK_SUB)) & ((1u << GSR_WALK_SUB) - 1u));
 }
 
 // optimizer step folded into k_preprocess_bwd (gsr_backward_adam): kernel-side form of gsr_fused_adam

@@ -283,9 +283,11 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
                                                     const uint32_t* __restrict__ depth_key,
                                                     const uint32_t* __restrict__ culled_any /* nullptr: lists not truncated */,
                                                     uint32_t frame_tag, uint32_t* __restrict__ meta, uint32_t margin_q8,
-                                                    uint32_t margin_add) {
+                                                    uint32_t margin_add, uint32_t* __restrict__ walk_cnt,
+                                                    uint32_t* __restrict__ walk_list, uint32_t* __restrict__ walk_of_tile) {
   __shared__ float4 s0[FWD_BATCH + 6], s1[FWD_BATCH + 6], s2[FWD_BATCH];  // +6: the prefetch may touch [n+5]
   __shared__ uint32_t s_need;
+  __shared__ uint32_t s_wave_last[4];
   __shared__ uint32_t smask[MASKED ? FWD_BATCH : 1];                      // (MASKED) reachable quadrants of every staged entry
   const int tile = blockIdx.x;
   // non-blocking forward: the frame's status words (flags, num_rendered, longest tile list - final since the previous
@@ -446,6 +448,24 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int grid_x, co
           tile_cutoff[tile] = 0xFFFFFFFFu;                  // the margin reaches past the whole list: nothing to cut
         }                                                   // (else: keep the wider cut-off this frame was rendered with)
       }
+    }
+  }
+  if (walk_cnt) {
+    // (round 4) The backward walks this tile's list up to the deepest contributor of any of its pixels.  The tile is filed under
+    // the class of that length (gsr_walk_class: a coarse logarithm) - one atomic per tile, spread over the launch - and
+    // k_render_bwd_tile takes the classes longest first: its launch ends with its longest walk, so the long walks must START
+    // first and the short ones fill the second round of resident waves (0.415 -> 0.38 ms at 1080p).
+    uint32_t m = last;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if (lane == 0) s_wave_last[w] = m;
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t walk = max(max(s_wave_last[0], s_wave_last[1]), max(s_wave_last[2], s_wave_last[3]));
+      const int cls = gsr_walk_class(walk);
+      walk_of_tile[tile] = walk;
+      const uint32_t r = atomicAdd(&walk_cnt[cls], 1u);
+      if (r < gridDim.x) walk_list[(size_t)cls * gridDim.x + r] = (uint32_t)tile;
     }
   }
   if (inside) {
@@ -671,7 +691,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
                                                         const float* __restrict__ dL_dinvdepth,
                                                         const uint32_t* __restrict__ slot_of_pos,
                                                         float4* __restrict__ igrad, const uint32_t* __restrict__ n_dev,
-                                                        uint32_t cap, int prio1, int prio2, int prio3) {
+                                                        uint32_t cap, int prio1, int prio2, int prio3,
+                                                        const uint32_t* __restrict__ walk_cnt,
+                                                        const uint32_t* __restrict__ walk_list,
+                                                        const uint32_t* __restrict__ walk_of_tile) {
   // (one object: the three arrays sit at fixed distances, so an entry's reads share ONE address register and differ in the
   // instruction's immediate offset - two v_add_u32 per walked entry less than three separate __shared__ arrays cost)
   __shared__ struct { float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH]; } stg;   // +2: the prefetch may touch [n+1]
@@ -688,7 +711,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
   // issued at once and consumed after the NEXT entry's visit, so their latency hides behind it.
   __shared__ float redbuf[(MASK ? 10 : 1) * 80];
 #endif
-  const int tile = blockIdx.x;
+  // (round 4) Workgroup b takes the b-th tile of the order "walk classes descending, inside a class as filed by the forward"
+  // (k_render_fwd): lane l holds the size of class l, a suffix sum over the 64 lanes gives the tiles in classes >= l, the class of
+  // position b is the highest one whose suffix sum exceeds b.  Which workgroup takes which tile does not enter any result.
+  int tile = blockIdx.x;
+  if (walk_cnt) {
+    // Two duties, two orders.  The entries BEHIND a tile's walk get zero records, hundreds per tile on scenes of large splats, and
+    // neighbouring tiles write them into the same Gaussians' record regions: in index order those partial-line writes combine in
+    // the caches, in walk order they do not (2 x splats: 0.53 -> 0.58 ms, 4K: 1.39 -> 1.55 with the zeros written by the walking
+    // workgroup).  So workgroup b writes the zeros of tile b - index order, as ever - and walks the b-th tile of the walk order.
+    {
+      const uint2 zr = ranges[blockIdx.x];
+      const int zlen = (int)(zr.y - zr.x);
+      const int zfrom = min(zlen, (int)walk_of_tile[blockIdx.x]);
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = zfrom + (int)threadIdx.x; i < zlen; i += 64) {
+        float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[zr.x + i];
+        dst[0] = z4; dst[1] = z4; dst[2] = z4;
+      }
+    }
+    uint32_t S = walk_cnt[threadIdx.x];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_down((int)S, d, 64);
+      if ((int)threadIdx.x + d < 64) S += o;
+    }
+    const uint64_t mcls = BALLOT(S > blockIdx.x);
+    if (mcls == 0ull) return;                                   // (every tile was filed exactly once: cannot happen)
+    const int cs = 63 - (int)__builtin_clzll(mcls);
+    const uint32_t above = cs < 63 ? (uint32_t)__builtin_amdgcn_readlane((int)S, cs + 1) : 0u;
+    tile = (int)walk_list[(size_t)cs * gridDim.x + (blockIdx.x - above)];
+  }
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int lane = threadIdx.x;
   const uint2 range = ranges[tile];
@@ -743,11 +796,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
     else if (toDo >= t1) __builtin_amdgcn_s_setprio(1);
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // entries beyond the deepest contributor of any pixel are never visited: their records are zeros
-  for (int i = toDo + lane; i < len; i += 64) {
-    float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + i];
-    dst[0] = z4; dst[1] = z4; dst[2] = z4;
-  }
+  // entries beyond the deepest contributor of any pixel are never visited: their records are zeros (with walk classes: written by
+  // the workgroup of the tile's index, above)
+  if (!walk_cnt)
+    for (int i = toDo + lane; i < len; i += 64) {
+      float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + i];
+      dst[0] = z4; dst[1] = z4; dst[2] = z4;
+    }
   int vzero;   // keeps the LDS base in a VGPR (see k_render_bwd)
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   const char* const stgv = reinterpret_cast<const char*>(&stg) + vzero;
@@ -1330,7 +1385,7 @@ void gsr_launch_render_fwd(const gsr_settings* s, int tiles, int grid_x, const u
                            const uint32_t* point_list, const float4* rec, float* out_color, float* out_invdepth,
                            float* final_T, uint32_t* n_contrib, const uint32_t* status_src, uint32_t* status_dst,
                            uint32_t* tile_cutoff, const uint32_t* depth_key, const uint32_t* culled_any, uint32_t frame_tag,
-                           uint32_t* meta, hipStream_t st) {
+                           uint32_t* meta, uint32_t* walk_cnt, uint32_t* walk_list, uint32_t* walk_of_tile, hipStream_t st) {
   // cut-off margin of the depth-truncated lists: 1.75 x the entries a tile needed + 48 (measured, profiles/r04_tile_cull.txt: 1.25 x + 16
   // flags 54 % of the frames of a run that trains from scratch, 1.5 x + 32 1 %, 1.75 x + 48 none; C3 and the 2 x splats scene)
   unsigned mq8 = 448, madd = 48;
@@ -1340,11 +1395,11 @@ void gsr_launch_render_fwd(const gsr_settings* s, int tiles, int grid_x, const u
   if (!(mk && !strcmp(mk, "1")))
     GSR_LAUNCH("render_fwd", (k_render_fwd<false, false>), dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
                ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr, status_src,
-               status_dst, tile_cutoff, depth_key, culled_any, frame_tag, meta, mq8, madd);
+               status_dst, tile_cutoff, depth_key, culled_any, frame_tag, meta, mq8, madd, walk_cnt, walk_list, walk_of_tile);
   else
     GSR_LAUNCH("render_fwd", (k_render_fwd<false, true>), dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x,
                ranges, point_list, rec, s->bg, out_color, out_invdepth, final_T, n_contrib, (uint32_t*)nullptr, status_src,
-               status_dst, tile_cutoff, depth_key, culled_any, frame_tag, meta, mq8, madd);
+               status_dst, tile_cutoff, depth_key, culled_any, frame_tag, meta, mq8, madd, walk_cnt, walk_list, walk_of_tile);
 }
 
 void gsr_launch_count_pairs(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges, const uint32_t* point_list,
@@ -1354,13 +1409,18 @@ void gsr_launch_count_pairs(const gsr_settings* s, int tiles, int grid_x, const 
   hipLaunchKernelGGL((k_render_fwd<true, false>), dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height, grid_x, ranges,
                      point_list, rec, s->bg, (float*)nullptr, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, pairs,
                      (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                     (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, 0u, 0u);
+                     (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, 0u, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
 }
 
 void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const uint2* ranges,
                            const uint32_t* point_list, const float4* rec, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dinvdepth,
-                           const uint32_t* slot_of_pos, float4* igrad, const uint32_t* n_dev, uint32_t cap, hipStream_t st) {
+                           const uint32_t* slot_of_pos, float4* igrad, const uint32_t* n_dev, uint32_t cap,
+                           const uint32_t* walk_cnt, const uint32_t* walk_list, const uint32_t* walk_of_tile, hipStream_t st) {
+  // GSR_BWD_LPT=0: tiles in index order (the A/B of the walk classes, profiles/r04_bwd_lpt_ab.txt)
+  if (const char* lp = getenv("GSR_BWD_LPT")) {
+    if (lp[0] == '0') walk_cnt = nullptr;
+  }
   // One wave per tile needs enough tiles to keep 1024 SIMDs busy: below ~6 tiles per SIMD (720p: 3600 tiles) the four-waves-per-tile form
   // (same results up to summation order inside a tile) has the shorter critical path.  GSR_BWD_FORM=quad|tile forces one.
   const char* form = getenv("GSR_BWD_FORM");          // (read per call: the tests switch forms inside one process)
@@ -1388,7 +1448,8 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
   if (!quad || (form && !strcmp(form, "tile"))) {
 #define GSR_BWD_TILE_LAUNCH(D, M)                                                                                          \
   GSR_LAUNCH("render_bwd", (k_render_bwd_tile<D, M>), dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height, grid_x, \
-             ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3)
+             ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3, \
+             walk_cnt, walk_list, walk_of_tile)
     if (dL_dinvdepth) {
       if (mask) GSR_BWD_TILE_LAUNCH(true, true); else GSR_BWD_TILE_LAUNCH(true, false);
     } else {

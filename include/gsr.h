@@ -32,6 +32,7 @@ extern "C" {
 #endif
 
 /* 7: gsr_debug_mx_reduce (the compositing backward's sums on the matrix pipe: opt-in form GSR_BWD_REDUCE=mfma, measured slower);
+ *    the image state carries the frame's walk classes (gsr_image_state_bytes grew; gsr_debug_walk_views);
  * 6: host_status word 0 bit 0 = radix-sort look-back time-out (was reserved; debug = 1 fails the call), gsr_debug_wave_reduce_pk,
  *    gsr_forward_async_culled (host_status word 0 bit 1 / word 6 = a truncated tile list was too short);
  * 5: gsr_fused_adam.dynamic + gsr_adam_set_dynamic (optimizer factors in device memory, for HIP-graph replay), gsr_l1_mean_*;
@@ -308,6 +309,13 @@ int gsr_debug_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
                          int32_t bits, int32_t vals_iota, const uint32_t* n_dev, void* tmp, void* stream);
 int gsr_debug_image_views(const void* image_state, int32_t image_width, int32_t image_height,
                           const float** final_T, const uint32_t** n_contrib);
+/* The walk classes a forward with a backward to follow leaves in the image state (ABI 7): walk_cnt[classes] = tiles per class,
+ * walk_list[classes][tiles] = the tiles of each class in the order their compositing workgroups finished, walk_of_tile[tiles] = the
+ * deepest contributor of any pixel of the tile = the number of list entries its backward walks; class = exponent and two leading
+ * mantissa bits of that number (walks below 4: the number itself; clamped at 65535).  k_render_bwd_tile takes the classes
+ * longest first (GSR_BWD_LPT=0: index order).  Returns the number of classes (64). */
+int gsr_debug_walk_views(const void* image_state, int32_t image_width, int32_t image_height, const uint32_t** walk_cnt,
+                         const uint32_t** walk_list, const uint32_t** walk_of_tile);
 
 /* ---- callers of the hot path that the reference also takes from native modules ---- */
 

@@ -156,4 +156,9 @@ def lowlevel_forward(raw, cam, deg, bg, antialiasing=False, device="cuda"):
     lib.gsr_debug_image_views(_C.ptr(img), W, H, C.byref(pi[0]), C.byref(pi[1]))
     out["final_T"] = _view(img, pi[0].value, W * H, torch.float32).view(H, W)
     out["n_contrib"] = _view(img, pi[1].value, W * H, torch.int32).view(H, W)
+    pw = [C.c_void_p() for _ in range(3)]
+    classes = lib.gsr_debug_walk_views(_C.ptr(img), W, H, C.byref(pw[0]), C.byref(pw[1]), C.byref(pw[2]))
+    out["walk_cnt"] = _view(img, pw[0].value, classes, torch.int32).numpy().view(np.uint32)
+    out["walk_list"] = _view(img, pw[1].value, classes * tiles, torch.int32).numpy().view(np.uint32).reshape(classes, tiles)
+    out["walk_of_tile"] = _view(img, pw[2].value, tiles, torch.int32).numpy().view(np.uint32)
     return out

@@ -461,6 +461,76 @@ def test_wave_reduction_primitive():
     assert torch.equal(o1, o2)
 
 
+def _walk_class(w):
+    """gsr_walk_class of csrc/gsr_common.h (4 classes per octave): exponent and two leading mantissa bits, clamped at 65535."""
+    w = min(int(w), 65535)
+    if w < 4:
+        return w
+    e = w.bit_length() - 1
+    return (e << 2) + ((w >> (e - 2)) & 3)
+
+
+@pytest.mark.parametrize("W,H,P,scale", [(208, 144, 6000, 0.8), (100, 52, 800, 2.5), (64, 48, 3, 1.0)])
+def test_walk_classes_of_a_frame(W, H, P, scale):
+    """Round 4: a forward with a backward to follow files every tile under the class of its walk length - the deepest contributor
+    of any of its pixels, i.e. the number of list entries the compositing backward replays for it - and k_render_bwd_tile takes the
+    classes longest first.  Straight from the C ABI (blocking path: the counters are cleared by a memset there): every tile is
+    filed exactly once, under the class of max(n_contrib) over its pixels, and walk_of_tile holds that maximum (the workgroup of a
+    tile's INDEX writes the zero records behind it).  Odd image sizes, tiles without instances (3 Gaussians), big splats."""
+    import numpy as np
+    raw = make_gaussians(P, 1, seed=77, scale_factor=scale)
+    cam = fibonacci_cameras(2, W, H, seed=78)[1]
+    out = lowlevel_forward(raw, cam, 1, torch.tensor([0.1, 0.2, 0.3]))
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    tiles = gx * gy
+    nc = out["n_contrib"].numpy()
+    want = np.zeros(tiles, dtype=np.int64)
+    for t in range(tiles):
+        ty, tx = divmod(t, gx)
+        want[t] = nc[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16].max()
+    assert np.array_equal(out["walk_of_tile"].astype(np.int64), want)
+    cnt = out["walk_cnt"].astype(np.int64)
+    assert int(cnt.sum()) == tiles
+    seen = []
+    for c in range(len(cnt)):
+        members = out["walk_list"][c, :cnt[c]].astype(np.int64)
+        assert all(_walk_class(want[t]) == c for t in members), (c, members[:8], want[members[:8]])
+        seen.extend(members.tolist())
+    assert sorted(seen) == list(range(tiles))
+    if P > 100:
+        assert int((cnt > 0).sum()) >= 3           # (the scene does spread over several classes)
+
+
+@pytest.mark.parametrize("depth,aa,P,scale", [(False, False, 6000, 0.8), (True, True, 6000, 0.8), (False, False, 40, 3.0)])
+def test_walk_order_changes_no_bit(depth, aa, P, scale):
+    """The order in which the one-wave-per-tile backward takes the tiles (walk classes, longest first; the zero records behind a
+    tile's walk written by the workgroup of the tile's index) must not enter any result: every gradient equals the index-order
+    launch's (GSR_BWD_LPT=0) bit for bit - also with the inverse-depth + anti-aliasing instantiation and on a scene most of whose
+    tiles are empty (40 big splats)."""
+    raw = make_gaussians(P, 2, seed=411, scale_factor=scale)
+    cam = fibonacci_cameras(3, 208, 144, seed=413)[1]
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    gc, gd = upstream_grads(cam.image_height, cam.image_width, depth=depth)
+    old = {k: os.environ.get(k) for k in ("GSR_BWD_FORM", "GSR_BWD_LPT")}
+    try:
+        os.environ["GSR_BWD_FORM"] = "tile"
+        os.environ["GSR_BWD_LPT"] = "0"
+        a = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
+        os.environ.pop("GSR_BWD_LPT")
+        b = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
+        c = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert float(b["grads"]["means3D"].abs().sum()) > 0
+    for k in a["grads"]:
+        assert torch.equal(a["grads"][k], b["grads"][k]), (k, float((a["grads"][k] - b["grads"][k]).abs().max()))
+        assert torch.equal(b["grads"][k], c["grads"][k]), k      # (and run to run: which workgroup takes which tile varies)
+
+
 def test_matrix_pipe_reduction_primitive():
     """Round 4 (opt-in form, GSR_BWD_REDUCE=mfma; measured slower, kept as evidence): k_render_bwd_tile_mx takes an entry's ten sums over the tile's 256 pixels on the matrix pipe (v_mfma_f32_16x16x4_f32
     against the tile's separable pixel basis, csrc/render.hip).  The hook runs that very stage-1 / stage-2 / LDS slot / record code
