@@ -501,9 +501,10 @@ def test_walk_classes_of_a_frame(W, H, P, scale):
         assert int((cnt > 0).sum()) >= 3           # (the scene does spread over several classes)
 
 
+@pytest.mark.parametrize("form", ["tile", "quad"])
 @pytest.mark.parametrize("depth,aa,P,scale", [(False, False, 6000, 0.8), (True, True, 6000, 0.8), (False, False, 40, 3.0)])
-def test_walk_order_changes_no_bit(depth, aa, P, scale):
-    """The order in which the one-wave-per-tile backward takes the tiles (walk classes, longest first; the zero records behind a
+def test_walk_order_changes_no_bit(depth, aa, P, scale, form):
+    """The order in which the compositing backward (both forms) takes the tiles (walk classes, longest first; the zero records behind a
     tile's walk written by the workgroup of the tile's index) must not enter any result: every gradient equals the index-order
     launch's (GSR_BWD_LPT=0) bit for bit - also with the inverse-depth + anti-aliasing instantiation and on a scene most of whose
     tiles are empty (40 big splats)."""
@@ -513,10 +514,10 @@ def test_walk_order_changes_no_bit(depth, aa, P, scale):
     gc, gd = upstream_grads(cam.image_height, cam.image_width, depth=depth)
     old = {k: os.environ.get(k) for k in ("GSR_BWD_FORM", "GSR_BWD_LPT")}
     try:
-        os.environ["GSR_BWD_FORM"] = "tile"
+        os.environ["GSR_BWD_FORM"] = form
         os.environ["GSR_BWD_LPT"] = "0"
         a = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
-        os.environ.pop("GSR_BWD_LPT")
+        os.environ["GSR_BWD_LPT"] = "1"             # (forced: a grid this small is left in index order by default)
         b = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
         c = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
     finally:
