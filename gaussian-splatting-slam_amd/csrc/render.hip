@@ -1457,7 +1457,9 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
   const bool quad = form ? !strcmp(form, "quad") : tiles < 6000;
   // (the walk order pays where a launch runs in several rounds of resident workgroups; a grid that is resident at once - 256 CUs x 5
   // four-wave workgroups - has no late starters to reorder: 256 tiles 0.054 -> 0.056 ms with it, 3600 tiles 0.166 -> 0.150)
-  if (tiles <= 1280) {
+  // ... nor does a launch of many rounds gain what its record gathers lose in locality (4K, 32 400 tiles = 6.3 rounds of one-wave
+  // workgroups: 1.381 -> 1.407 ms with the walk order); GSR_BWD_LPT=1 forces the order for any grid
+  if (tiles <= 1280 || tiles > 24000) {
     const char* lp = getenv("GSR_BWD_LPT");
     if (!(lp && lp[0] == '1')) walk_cnt = nullptr;
   }
