@@ -510,6 +510,15 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
   // order: neighbouring tiles' partial-line writes combine) and composites the b-th tile of the order "longest walk first"; every
   // wave works the mapping out for itself (a 64-lane suffix sum of the class sizes: no barrier)
   int tile = blockIdx.x;
+  uint32_t csum = walk_cnt ? walk_cnt[threadIdx.x & 63] : 0u;
+  if (walk_cnt) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_down((int)csum, d, 64);
+      if ((int)(threadIdx.x & 63) + d < 64) csum += o;
+    }
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)csum) != gridDim.x) walk_cnt = nullptr;   // (see k_render_bwd_tile)
+  }
   if (walk_cnt) {
     {
       const uint2 zr = ranges[blockIdx.x];
@@ -521,17 +530,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
         dst[0] = z4; dst[1] = z4; dst[2] = z4;
       }
     }
-    uint32_t S = walk_cnt[threadIdx.x & 63];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_down((int)S, d, 64);
-      if ((int)(threadIdx.x & 63) + d < 64) S += o;
-    }
-    const uint64_t mcls = BALLOT(S > blockIdx.x);
-    if (mcls == 0ull) return;                                   // (every tile was filed exactly once: cannot happen)
+    const uint64_t mcls = BALLOT(csum > blockIdx.x);
     const int cs = 63 - (int)__builtin_clzll(mcls);
-    const uint32_t above = cs < 63 ? (uint32_t)__builtin_amdgcn_readlane((int)S, cs + 1) : 0u;
-    tile = (int)walk_list[(size_t)cs * gridDim.x + (blockIdx.x - above)];
+    const uint32_t above = cs < 63 ? (uint32_t)__builtin_amdgcn_readlane((int)csum, cs + 1) : 0u;
+    tile = (int)min(walk_list[(size_t)cs * gridDim.x + (blockIdx.x - above)], gridDim.x - 1u);
   }
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -744,6 +746,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
   // (k_render_fwd): lane l holds the size of class l, a suffix sum over the 64 lanes gives the tiles in classes >= l, the class of
   // position b is the highest one whose suffix sum exceeds b.  Which workgroup takes which tile does not enter any result.
   int tile = blockIdx.x;
+  // (class sizes that do not add up to the grid - an image state no forward-with-backward has filed - mean index order, not a fault)
+  uint32_t csum = walk_cnt ? walk_cnt[threadIdx.x] : 0u;
+  if (walk_cnt) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_down((int)csum, d, 64);
+      if ((int)threadIdx.x + d < 64) csum += o;
+    }
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)csum) != gridDim.x) walk_cnt = nullptr;
+  }
   if (walk_cnt) {
     // Two duties, two orders.  The entries BEHIND a tile's walk get zero records, hundreds per tile on scenes of large splats, and
     // neighbouring tiles write them into the same Gaussians' record regions: in index order those partial-line writes combine in
@@ -759,17 +771,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
         dst[0] = z4; dst[1] = z4; dst[2] = z4;
       }
     }
-    uint32_t S = walk_cnt[threadIdx.x];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_down((int)S, d, 64);
-      if ((int)threadIdx.x + d < 64) S += o;
-    }
-    const uint64_t mcls = BALLOT(S > blockIdx.x);
-    if (mcls == 0ull) return;                                   // (every tile was filed exactly once: cannot happen)
+    const uint64_t mcls = BALLOT(csum > blockIdx.x);                // (not empty: the sizes add up to the grid)
     const int cs = 63 - (int)__builtin_clzll(mcls);
-    const uint32_t above = cs < 63 ? (uint32_t)__builtin_amdgcn_readlane((int)S, cs + 1) : 0u;
-    tile = (int)walk_list[(size_t)cs * gridDim.x + (blockIdx.x - above)];
+    const uint32_t above = cs < 63 ? (uint32_t)__builtin_amdgcn_readlane((int)csum, cs + 1) : 0u;
+    tile = (int)min(walk_list[(size_t)cs * gridDim.x + (blockIdx.x - above)], gridDim.x - 1u);
   }
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int lane = threadIdx.x;

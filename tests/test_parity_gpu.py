@@ -623,6 +623,38 @@ def test_low_level_C_call_forms():
     assert torch.equal(d_op.cpu(), ref["grads"]["opacities"]) and torch.equal(d_sc.cpu(), ref["grads"]["scales"])
     vis = _C.mark_visible(inp["means3D"], cam.world_view_transform.cuda(), cam.full_proj_transform.cuda())
     assert vis.dtype == torch.bool and int(vis.sum()) >= int((radii > 0).sum())
+    # An image state whose walk classes do not add up to the tile grid (here: wiped by the caller) is composited backward in
+    # index order - same gradients, no out-of-range tile (round 4; forced for this 24-tile image, small grids are index order anyway)
+    import ctypes as C
+    pw = [C.c_void_p() for _ in range(3)]
+    classes = _C.lib().gsr_debug_walk_views(_C.ptr(img), 96, 64, C.byref(pw[0]), C.byref(pw[1]), C.byref(pw[2]))
+    off = pw[0].value - img.data_ptr()
+    assert int(img[off:off + 4 * classes].view(torch.int32).sum()) == 6 * 4       # (every one of the 24 tiles was filed)
+    old = {k: os.environ.get(k) for k in ("GSR_BWD_LPT", "GSR_BWD_FORM")}
+    try:
+        os.environ["GSR_BWD_LPT"] = "1"
+        for form in ("tile", "quad"):
+            os.environ["GSR_BWD_FORM"] = form
+            outs = []
+            for wipe in (False, True):
+                if wipe:
+                    img[off:off + 4 * classes] = 0
+                outs.append(_C.rasterize_gaussians_backward(
+                    bg.cuda(), inp["means3D"], radii, e, inp["opacities"], inp["scales"], inp["rotations"], 1.0, e,
+                    cam.world_view_transform.cuda(), cam.full_proj_transform.cuda(), math.tan(cam.FoVx * 0.5),
+                    math.tan(cam.FoVy * 0.5), gc.cuda(), gd.cuda(), inp["shs"], 3, cam.camera_center.cuda(), geom, R, binning,
+                    img, False, False))
+            for x, y in zip(*outs):
+                assert torch.equal(x, y)
+            if form == "tile":          # (the quad form is what the reference run above used at this size)
+                continue
+            assert torch.equal(outs[0][3].cpu(), ref["grads"]["means3D"])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("mode", ["sh", "dc"])
