@@ -38,6 +38,28 @@ VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2.0
 _T0 = time.time()
 
 
+_REAL_STDOUT_FD = None
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (librccl's version banner at communicator
+    creation), so descriptor 1 is pointed at stderr for the life of the process and the line goes out through a duplicate of
+    the original descriptor."""
+    global _REAL_STDOUT_FD
+    if _REAL_STDOUT_FD is None:
+        sys.stdout.flush()
+        _REAL_STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit_json_line(line):
+    sys.stdout.flush()
+    fd = _REAL_STDOUT_FD if _REAL_STDOUT_FD is not None else 1
+    data = (line + "\n").encode()
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def log(msg):
     """progress to stderr (stdout carries exactly one JSON line)"""
     print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -68,6 +90,8 @@ def build_scene(args, device, rank, world):
     teacher_raw.xyz += 0.002 * torch.randn(teacher_raw.xyz.shape, generator=gen)
     teacher = GaussianModel.from_raw(teacher_raw.to(device), requires_grad=False)
     my_views = list(range(len(cams)))[rank::world]
+    if not my_views:                       # fewer views than ranks (a one-view config under a launcher): share one
+        my_views = [rank % len(cams)]
     log(f"scene generated: P={cfg['P']} views={len(cams)}")
     gts, depth_gts = {}, ({} if cfg.get("depth_grad") else None)
 
@@ -358,6 +382,7 @@ def main():
         log("no launcher detected: " + " ".join(cmd))
         sys.exit(subprocess.call(cmd))
 
+    _claim_stdout()
     if args.exchange == "auto":
         args.exchange = "sh_rank1" if max(1, args.views_per_step) == 1 and args.optimizer in ("hip", "hip_fused", "torch") \
             else "allreduce"
@@ -610,10 +635,16 @@ def main():
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
 
     if rank == 0:
-        print(json.dumps(result))
+        # ONE line on the real stdout (everything else that writes to descriptor 1 - RCCL prints a version banner there - was sent
+        # to stderr at start-up), written and flushed before the process group is touched again: a teardown that aborts would
+        # otherwise take a block-buffered line with it
+        _emit_json_line(json.dumps(result))
     if world > 1 or single_rank_group:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:      # the number is out; a failing teardown must not turn the run into an error
+            log(f"process-group teardown: {e!r}")
 
 
 if __name__ == "__main__":
