@@ -23,6 +23,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-slam_amd"))
 sys.path.insert(0, ROOT)
+# (the pool's host driver supports dmabuf IPC only: without this RCCL's buffer sharing between the ranks of a node fails with
+# hipIpcGetMemHandle "invalid argument"; the image exports it already - kept for environments that build their own)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
