@@ -431,6 +431,39 @@ def test_lowlevel_forward_ignores_state_contents_and_reports_prefiltered_culls(t
     assert rc == 0 and (int(status[0]) >> 32) & 1 == 0 and n > 0
 
 
+def test_default_path_files_the_walk_classes_of_every_frame():
+    """Round 4: in the default (tile-local, non-blocking) forward the walk-class counters are cleared by the first workgroup of
+    the per-tile ordering kernel, not by a memset.  If that clearing were lost the backward would find class sizes that do not add
+    up to the grid and fall back to index order - same bits, no test would fail, only the speed would be gone.  So look at the
+    state the Python path really used: after several training-mode renders of different views through one workspace pool, every
+    workspace's counters add up to exactly one frame's tiles."""
+    import ctypes as C
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C, _workspace as ws
+    if ws._BINNING != "tile":
+        pytest.skip("GSR_BINNING=global")
+    raw = make_gaussians(4000, 1, seed=901, scale_factor=1.0)
+    cams = fibonacci_cameras(5, 208, 144, seed=902)
+    bg = torch.tensor([0.1, 0.1, 0.1])
+    gc, gd = upstream_grads(144, 208, depth=False)
+    for cam in cams:                                             # (forward + backward each: the pool recycles its workspaces)
+        run_hip(raw, cam, 1, bg, gc=gc, gd=None)
+    torch.cuda.synchronize()
+    pool = ws.pool(torch.device("cuda", torch.cuda.current_device()))
+    tiles = ((208 + 15) // 16) * ((144 + 15) // 16)
+    seen = 0
+    for w in pool.free:
+        if w.img is None or w.img.numel() < _C.lib().gsr_image_state_bytes(208, 144):
+            continue
+        pw = [C.c_void_p() for _ in range(3)]
+        classes = _C.lib().gsr_debug_walk_views(_C.ptr(w.img), 208, 144, C.byref(pw[0]), C.byref(pw[1]), C.byref(pw[2]))
+        off = pw[0].value - w.img.data_ptr()
+        cnt = w.img[off:off + 4 * classes].view(torch.int32).cpu()
+        assert int(cnt.sum()) == tiles, (cnt.tolist(), tiles)
+        seen += 1
+    assert seen >= 1
+
+
 def test_parity_suite_with_the_other_backward_form_and_other_forward_modes():
     """The two forms of the compositing backward (one wave per tile from 6000 tiles up, four waves per tile below) are chosen by
     image size, so the small-image parity tests only ever see the four-wave form.  Re-run the core parity tests in a child
