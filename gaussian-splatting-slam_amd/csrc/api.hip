@@ -108,6 +108,7 @@ static int debug_sync(const gsr_settings* s, hipStream_t st, const char* stage, 
 // per-kernel profiling (HIP events on the launch stream)
 // ---------------------------------------------------------------------------------------------------
 int g_gsr_profile_on = 0;
+unsigned g_gsr_flags_min_r = GSR_FLAGS_MIN_R;     // frames with at least this many instances flag their gradient records (gsr_common.h)
 namespace {
 struct Pending { const char* name; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -260,7 +261,8 @@ size_t gsr_binning_state_bytes(int32_t P, int32_t W, int32_t H, int64_t R) {
 }
 size_t gsr_backward_scratch_bytes(int32_t P, int64_t R) {
   (void)P;
-  return gsr_align((size_t)(R < 1 ? 1 : R) * 16 * GSR_IGRAD_F4);
+  const size_t cap = (size_t)(R < 1 ? 1 : R);
+  return gsr_igrad_bytes(cap) + gsr_align(cap + 16); // records + one validity byte per emission slot (gsr_common.h; + the reader's over-read)
 }
 
 // Colour pass (SH -> RGB, the HBM-heavy half of the projection) on a library-owned side stream, concurrent with the depth sort /
@@ -942,6 +944,12 @@ int gsr_debug_walk_views(const void* image_state, int32_t W, int32_t H, const ui
 }
 
 void gsr_profile_enable(int32_t on) { g_gsr_profile_on = on ? 1 : 0; }
+
+int64_t gsr_debug_set_flags_min_r(int64_t min_instances) {
+  const int64_t old = (int64_t)g_gsr_flags_min_r;
+  if (min_instances >= 0) g_gsr_flags_min_r = min_instances > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)min_instances;
+  return old;
+}
 
 void gsr_profile_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -619,13 +619,28 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
     float* __restrict__ dL_ddc, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dcov3D, float* __restrict__ st_accum, float* __restrict__ st_denom,
-    float* __restrict__ st_max_radii, const GsrAdamArgs A_in) {
+    float* __restrict__ st_max_radii, const GsrAdamArgs A_in, uint32_t flags_min_r) {
   extern __shared__ __attribute__((aligned(16))) float sh_lds[];
   const GsrAdamArgs A = ADAM ? gsr_adam_resolve(A_in) : A_in;
   __shared__ int32_t need_sh[BT];
   const int S = 3 * sh_stride, Sp = S | 1;
   const size_t row0 = (size_t)blockIdx.x * BT;
   const int rows = (int)min((size_t)BT, (size_t)P - row0);
+  // (round 4) where this thread's gradient records start, how many there are, and the validity flags of the first sixteen - asked
+  // for HERE so that they are on their way while the coefficient rows are staged below (the record reads depend on them)
+  uint32_t pre_s0 = 0u, pre_n = 0u, pre_fw[4] = {0u, 0u, 0u, 0u};
+  {
+    const int pidx = (int)min((size_t)(blockIdx.x * BT + threadIdx.x), (size_t)P - 1);
+    // (both words asked for at once - the count is not waited for before the start slot is requested; a Gaussian without instances
+    // has a stale start slot, which is then not used)
+    const uint32_t tt = tiles_touched[pidx], ss = slot_start[pidx];
+    if (!gsr_overflowed(n_dev, cap) && tt > 0) {
+      const uint32_t n_eff = gsr_eff_n(n_dev, cap);
+      pre_s0 = ss;
+      pre_n = pre_s0 < n_eff ? min(tt, n_eff - pre_s0) : 0u;
+      if (pre_n && gsr_flags_on(n_dev, cap, flags_min_r)) __builtin_memcpy(pre_fw, gsr_igrad_flags(igrad, cap) + pre_s0, 16);
+    }
+  }
   if (STAGE) {
     // rows to fetch: those with instances (their coefficients enter the gradient); with the optimizer folded in, every
     // row that will be UPDATED (all of them / the visible ones), since the update reads the parameter from the staged copy
@@ -665,31 +680,61 @@ __global__ __launch_bounds__(BT) void k_preprocess_bwd(
 #pragma unroll
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
     // (a non-blocking forward whose instance count exceeded the binning capacity dropped the slots >= n_eff: no records)
-    const uint32_t n_eff = gsr_eff_n(n_dev, cap);
-    const uint32_t s0 = slot_start[idx];
-    const uint32_t n = s0 < n_eff ? min(tiles_touched[idx], n_eff - s0) : 0u;
+    const uint32_t s0 = pre_s0, n = pre_n;      // (idx == the row the prologue looked at: an active thread's own)
     // this Gaussian's records are contiguous (slot order): stream them, 4 records in flight per thread.
     // Summation order = slot order (deterministic).
     const float4* rows = igrad + (size_t)GSR_IGRAD_F4 * s0;
-    uint32_t it = 0;
-    for (; it + 4 <= n; it += 4) {
-      float4 q[12];
+    // (round 4) one validity byte per slot: an instance behind its tile's walk has no record (it would be all zeros) - the bytes
+    // of a Gaussian's slots are contiguous like its records
+    const unsigned char* fl = gsr_igrad_flags(igrad, cap) + s0;
+    const bool flags_on = gsr_flags_on(n_dev, cap, flags_min_r);   // (grid-uniform; off: every slot holds a record, zeros included)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // The flags of sixteen slots come in ONE load (from wherever the Gaussian's slots start: the read may run up to fifteen bytes
+    // past them - the next Gaussian's flags, or the array's padding, gsr_backward_scratch_bytes), then four records per trip, masked
+    // by the count: one memory round trip per trip as before the flags (a flag load in front of every trip cost 100 k Gaussians
+    // with 13 instances each 12 us).
+    for (uint32_t it0 = 0; it0 < n; it0 += 16) {
+      uint32_t fw[4];
+      if (it0 == 0) { fw[0] = pre_fw[0]; fw[1] = pre_fw[1]; fw[2] = pre_fw[2]; fw[3] = pre_fw[3]; }
+      else if (flags_on) __builtin_memcpy(fw, fl + it0, 16);
+      else fw[0] = fw[1] = fw[2] = fw[3] = 0u;
 #pragma unroll
-      // (plain loads on purpose: the records were just written by the render backward and are largely still in the
-      // infinity cache - streaming hints on either side cost 35 % here)
-      for (int u = 0; u < 12; u++) q[u] = rows[3 * (size_t)it + u];
+      for (int t = 0; t < 4; t++) {
+        const uint32_t it = it0 + 4 * t;
+        if (it >= n) break;
+        float4 q[12];
+        if (!flags_on) {
+          // (small frames: the round-3 form - every slot was written, zeros included; nothing to wait for in front of the reads)
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        acc[0] += q[3 * u].x; acc[1] += q[3 * u].y; acc[2] += q[3 * u].z; acc[3] += q[3 * u].w;
-        acc[4] += q[3 * u + 1].x; acc[5] += q[3 * u + 1].y; acc[6] += q[3 * u + 1].z; acc[7] += q[3 * u + 1].w;
-        acc[8] += q[3 * u + 2].x; acc[9] += q[3 * u + 2].y;
+          for (int u = 0; u < 4; u++)
+            if (it + u < n) {
+              q[3 * u] = rows[3 * (size_t)(it + u)];
+              q[3 * u + 1] = rows[3 * (size_t)(it + u) + 1];
+              q[3 * u + 2] = rows[3 * (size_t)(it + u) + 2];
+            } else {
+              q[3 * u] = q[3 * u + 1] = q[3 * u + 2] = z4;
+            }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 12; u++) q[u] = z4;
+          // (plain loads on purpose: the records were just written by the render backward and are largely still in the
+          // infinity cache - streaming hints on either side cost 35 % here.  Explicit branches: written as `flag ? load : zero`
+          // the compiler selects between POINTERS and reads the records dword by dword through flat loads.)
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (((fw[t] >> (8 * u)) & 0xFFu) != 0u && it + u < n) {
+              q[3 * u] = rows[3 * (size_t)(it + u)];
+              q[3 * u + 1] = rows[3 * (size_t)(it + u) + 1];
+              q[3 * u + 2] = rows[3 * (size_t)(it + u) + 2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          acc[0] += q[3 * u].x; acc[1] += q[3 * u].y; acc[2] += q[3 * u].z; acc[3] += q[3 * u].w;
+          acc[4] += q[3 * u + 1].x; acc[5] += q[3 * u + 1].y; acc[6] += q[3 * u + 1].z; acc[7] += q[3 * u + 1].w;
+          acc[8] += q[3 * u + 2].x; acc[9] += q[3 * u + 2].y;
+        }
       }
-    }
-    for (; it < n; it++) {
-      const float4 r0 = rows[3 * (size_t)it + 0], r1 = rows[3 * (size_t)it + 1], r2 = rows[3 * (size_t)it + 2];
-      acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
-      acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
-      acc[8] += r2.x; acc[9] += r2.y;
     }
     const float g_op_eff = acc[5];
     float g_rgb[3] = {acc[6], acc[7], acc[8]};
@@ -1284,7 +1329,7 @@ int gsr_launch_preprocess_bwd(const gsr_settings* s, const gsr_gaussians* g, con
       (const uint32_t*)(geom + L.tiles_touched), (const uint32_t*)(geom + L.slot_start), igrad,                       \
       (const uint32_t*)(geom + L.meta) + 2, cap, gr->dL_dmeans3D,                                                      \
       gr->dL_dmeans2D, gr->dL_ddc, gr->dL_dshs, gr->dL_dcolors, gr->dL_dopacities, gr->dL_dscales, gr->dL_drotations, \
-      gr->dL_dcov3D, gr->xyz_gradient_accum, gr->denom, gr->max_radii2D, A
+      gr->dL_dcov3D, gr->xyz_gradient_accum, gr->denom, gr->max_radii2D, A, g_gsr_flags_min_r
 #define GSR_PRE_BWD(ST, AD, BT_)                                                                                       \
   do {                                                                                                                 \
     if (lds > 48 * 1024)                                                                                               \

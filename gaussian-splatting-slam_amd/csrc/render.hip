@@ -498,9 +498,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
                                                     float4* __restrict__ igrad, const uint32_t* __restrict__ n_dev,
                                                     uint32_t cap, const uint32_t* __restrict__ walk_cnt,
                                                     const uint32_t* __restrict__ walk_list,
-                                                    const uint32_t* __restrict__ walk_of_tile) {
+                                                    const uint32_t* __restrict__ walk_of_tile, uint32_t flags_min_r) {
   __shared__ float4 s0[BWD_BATCH + 6], s1[BWD_BATCH + 6], s2[BWD_BATCH];  // +6: the prefetch may touch [n+5]
   if (gsr_overflowed(n_dev, cap)) return;   // grid-uniform: a truncated frame teaches nothing (gsr_common.h)
+  unsigned char* const iflags = gsr_igrad_flags(igrad, cap);
+  const bool flags_on = gsr_flags_on(n_dev, cap, flags_min_r);   // (grid-uniform: validity bytes instead of zero records, gsr_common.h)
   // one private slab per wave: no LDS atomics, and the 4 partial sums are added in a FIXED order at flush time,
   // so gradients are bitwise reproducible
   __shared__ float4 slab[4][BWD_BATCH * GSR_IGRAD_F4];
@@ -524,10 +526,13 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       const uint2 zr = ranges[blockIdx.x];
       const int zlen = (int)(zr.y - zr.x);
       const int zfrom = min(zlen, (int)walk_of_tile[blockIdx.x]);
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int i = zfrom + (int)threadIdx.x; i < zlen; i += 256) {
-        float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[zr.x + i];
-        dst[0] = z4; dst[1] = z4; dst[2] = z4;
+        const uint32_t zslot = slot_of_pos[zr.x + i];
+        if (flags_on) iflags[zslot] = 0;      // (no record: gsr_common.h GSR_IGRAD_F4)
+        else {
+          float4* dst = igrad + (size_t)GSR_IGRAD_F4 * zslot;
+          dst[0] = dst[1] = dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
     }
     const uint64_t mcls = BALLOT(csum > blockIdx.x);
@@ -574,8 +579,12 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
   // are fire-and-forget.  (With walk classes the zero records were written above, by the workgroup of the tile's index.)
   if (!walk_cnt)
     for (int i = toDo + tid; i < len; i += 256) {
-      float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + i];
-      dst[0] = z4; dst[1] = z4; dst[2] = z4;
+      const uint32_t zslot = slot_of_pos[range.x + i];
+      if (flags_on) iflags[zslot] = 0;      // (no record: gsr_common.h GSR_IGRAD_F4)
+      else {
+        float4* dst = igrad + (size_t)GSR_IGRAD_F4 * zslot;
+        dst[0] = dst[1] = dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 
   const int rounds = (toDo + BWD_BATCH - 1) / BWD_BATCH;
@@ -684,7 +693,9 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int grid_x, co
       r.z = ((a0.z + a1.z) + a2.z) + a3.z;
       r.w = ((a0.w + a1.w) + a2.w) + a3.w;
       const int e = toDo - 1 - (b * BWD_BATCH + j);
-      igrad[(size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + e] + part] = r;
+      const uint32_t slot = slot_of_pos[range.x + e];
+      igrad[(size_t)GSR_IGRAD_F4 * slot + part] = r;
+      if (flags_on && part == 0) iflags[slot] = 1;
     }
   }
 }
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
                                                         uint32_t cap, int prio1, int prio2, int prio3,
                                                         const uint32_t* __restrict__ walk_cnt,
                                                         const uint32_t* __restrict__ walk_list,
-                                                        const uint32_t* __restrict__ walk_of_tile) {
+                                                        const uint32_t* __restrict__ walk_of_tile, uint32_t flags_min_r) {
   // (one object: the three arrays sit at fixed distances, so an entry's reads share ONE address register and differ in the
   // instruction's immediate offset - two v_add_u32 per walked entry less than three separate __shared__ arrays cost)
   __shared__ struct { float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH]; } stg;   // +2: the prefetch may touch [n+1]
@@ -733,6 +744,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
   float4 (&s1)[BWD1_BATCH + 2] = stg.s1;
   float4 (&s2)[BWD1_BATCH] = stg.s2;
   if (gsr_overflowed(n_dev, cap)) return;   // grid-uniform: a truncated frame teaches nothing (gsr_common.h)
+  unsigned char* const iflags = gsr_igrad_flags(igrad, cap);
+  const bool flags_on = gsr_flags_on(n_dev, cap, flags_min_r);   // (grid-uniform: validity bytes instead of zero records, gsr_common.h)
   __shared__ float4 outb[BWD1_BATCH * GSR_IGRAD_F4];                          // the batch's gradient records
 #if BWD_LDS_REDUCE
   // The first two stages of the halving tree (lanes l + l^32, rows r + r^1: six v_permlane swaps at 3.2 x the price of a plain
@@ -765,10 +778,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
       const uint2 zr = ranges[blockIdx.x];
       const int zlen = (int)(zr.y - zr.x);
       const int zfrom = min(zlen, (int)walk_of_tile[blockIdx.x]);
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int i = zfrom + (int)threadIdx.x; i < zlen; i += 64) {
-        float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[zr.x + i];
-        dst[0] = z4; dst[1] = z4; dst[2] = z4;
+        const uint32_t zslot = slot_of_pos[zr.x + i];
+        if (flags_on) iflags[zslot] = 0;      // (no record: gsr_common.h GSR_IGRAD_F4)
+        else {
+          float4* dst = igrad + (size_t)GSR_IGRAD_F4 * zslot;
+          dst[0] = dst[1] = dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
     }
     const uint64_t mcls = BALLOT(csum > blockIdx.x);                // (not empty: the sizes add up to the grid)
@@ -834,8 +850,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
   // the workgroup of the tile's index, above)
   if (!walk_cnt)
     for (int i = toDo + lane; i < len; i += 64) {
-      float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + i];
-      dst[0] = z4; dst[1] = z4; dst[2] = z4;
+      const uint32_t zslot = slot_of_pos[range.x + i];
+      if (flags_on) iflags[zslot] = 0;      // (no record: gsr_common.h GSR_IGRAD_F4)
+      else {
+        float4* dst = igrad + (size_t)GSR_IGRAD_F4 * zslot;
+        dst[0] = dst[1] = dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   int vzero;   // keeps the LDS base in a VGPR (see k_render_bwd)
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
@@ -1099,7 +1119,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_TILE_WAV
     for (int q = lane; q < n * GSR_IGRAD_F4; q += 64) {
       const int j = q / GSR_IGRAD_F4, part = q - j * GSR_IGRAD_F4;
       const int e = toDo - 1 - (b * BWD1_BATCH + j);
-      igrad[(size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + e] + part] = outb[q];
+      const uint32_t slot = slot_of_pos[range.x + e];
+      igrad[(size_t)GSR_IGRAD_F4 * slot + part] = outb[q];
+      if (flags_on && part == 0) iflags[slot] = 1;
     }
   }
 }
@@ -1246,9 +1268,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_MX_WAVES
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dinvdepth,
     const uint32_t* __restrict__ slot_of_pos, float4* __restrict__ igrad, const uint32_t* __restrict__ n_dev, uint32_t cap,
-    int prio1, int prio2, int prio3) {
+    int prio1, int prio2, int prio3, uint32_t flags_min_r) {
   __shared__ float4 s0[BWD1_BATCH + 2], s1[BWD1_BATCH + 2], s2[BWD1_BATCH];
   if (gsr_overflowed(n_dev, cap)) return;
+  unsigned char* const iflags = gsr_igrad_flags(igrad, cap);
+  const bool flags_on = gsr_flags_on(n_dev, cap, flags_min_r);   // (grid-uniform: validity bytes instead of zero records, gsr_common.h)
   __shared__ float4 qbuf[BWD1_BATCH * GSR_MX_SLOT_F4];
   const int tile = blockIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -1299,8 +1323,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_MX_WAVES
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = toDo + lane; i < len; i += 64) {   // entries behind the deepest contributor: zero records
-    float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot_of_pos[range.x + i];
-    dst[0] = z4; dst[1] = z4; dst[2] = z4;
+    const uint32_t zslot = slot_of_pos[range.x + i];
+    if (flags_on) iflags[zslot] = 0;      // (no record: gsr_common.h GSR_IGRAD_F4)
+    else {
+      float4* dst = igrad + (size_t)GSR_IGRAD_F4 * zslot;
+      dst[0] = dst[1] = dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   int vzero;
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
@@ -1411,6 +1439,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_MX_WAVES
       }
       float4* dst = igrad + (size_t)GSR_IGRAD_F4 * slot;
       dst[0] = o0; dst[1] = o1; dst[2] = o2;
+      if (flags_on) iflags[slot] = 1;
     }
   }
 }
@@ -1481,17 +1510,17 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
   if ((!quad || (form && !strcmp(form, "tile"))) && mx) {
     if (dL_dinvdepth)
       GSR_LAUNCH("render_bwd", (k_render_bwd_tile_mx<true>), dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height, grid_x,
-                 ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3);
+                 ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3, g_gsr_flags_min_r);
     else
       GSR_LAUNCH("render_bwd", (k_render_bwd_tile_mx<false>), dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height, grid_x,
-                 ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3);
+                 ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3, g_gsr_flags_min_r);
     return;
   }
   if (!quad || (form && !strcmp(form, "tile"))) {
 #define GSR_BWD_TILE_LAUNCH(D, M)                                                                                          \
   GSR_LAUNCH("render_bwd", (k_render_bwd_tile<D, M>), dim3(tiles), dim3(64), 0, st, s->image_width, s->image_height, grid_x, \
              ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap, p1, p2, p3, \
-             walk_cnt, walk_list, walk_of_tile)
+             walk_cnt, walk_list, walk_of_tile, g_gsr_flags_min_r)
     if (dL_dinvdepth) {
       if (mask) GSR_BWD_TILE_LAUNCH(true, true); else GSR_BWD_TILE_LAUNCH(true, false);
     } else {
@@ -1503,9 +1532,9 @@ void gsr_launch_render_bwd(const gsr_settings* s, int tiles, int grid_x, const u
   if (dL_dinvdepth)
     GSR_LAUNCH("render_bwd", k_render_bwd<true>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height,
                grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap,
-               walk_cnt, walk_list, walk_of_tile);
+               walk_cnt, walk_list, walk_of_tile, g_gsr_flags_min_r);
   else
     GSR_LAUNCH("render_bwd", k_render_bwd<false>, dim3(tiles), dim3(256), 0, st, s->image_width, s->image_height,
                grid_x, ranges, point_list, rec, s->bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, slot_of_pos, igrad, n_dev, cap,
-               walk_cnt, walk_list, walk_of_tile);
+               walk_cnt, walk_list, walk_of_tile, g_gsr_flags_min_r);
 }

@@ -105,6 +105,7 @@ EXPORTS = {
     "gsr_debug_radix_sort": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_image_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p)]),
+    "gsr_debug_set_flags_min_r": (C.c_int64, [C.c_int64]),
     "gsr_debug_walk_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p)]),
     "gsr_fused_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),

@@ -32,7 +32,8 @@ extern "C" {
 #endif
 
 /* 7: gsr_debug_mx_reduce (the compositing backward's sums on the matrix pipe: opt-in form GSR_BWD_REDUCE=mfma, measured slower);
- *    the image state carries the frame's walk classes (gsr_image_state_bytes grew; gsr_debug_walk_views);
+ *    the image state carries the frame's walk classes (gsr_image_state_bytes grew; gsr_debug_walk_views); the backward's scratch
+ *    carries validity flags of the gradient records (gsr_backward_scratch_bytes grew; gsr_debug_set_flags_min_r);
  * 6: host_status word 0 bit 0 = radix-sort look-back time-out (was reserved; debug = 1 fails the call), gsr_debug_wave_reduce_pk,
  *    gsr_forward_async_culled (host_status word 0 bit 1 / word 6 = a truncated tile list was too short);
  * 5: gsr_fused_adam.dynamic + gsr_adam_set_dynamic (optimizer factors in device memory, for HIP-graph replay), gsr_l1_mean_*;
@@ -314,6 +315,11 @@ int gsr_debug_image_views(const void* image_state, int32_t image_width, int32_t 
  * deepest contributor of any pixel of the tile = the number of list entries its backward walks; class = exponent and two leading
  * mantissa bits of that number (walks below 4: the number itself; clamped at 65535).  k_render_bwd_tile takes the classes
  * longest first (GSR_BWD_LPT=0: index order).  Returns the number of classes (64). */
+/* From how many tile instances on a frame's per-instance gradient records carry validity flags (one byte per emission slot behind
+ * the records of the backward's scratch buffer: an instance behind its tile's walk gets no all-zero record, and the projection
+ * backward reads none).  Default 2 500 000 (smaller frames keep the zero records: there the flags are one more link in a
+ * latency-bound kernel).  Tests force either form: 0 = always, 2^32 - 1 = never; negative: only report.  Returns the previous value. */
+int64_t gsr_debug_set_flags_min_r(int64_t min_instances);
 int gsr_debug_walk_views(const void* image_state, int32_t image_width, int32_t image_height, const uint32_t** walk_cnt,
                          const uint32_t** walk_list, const uint32_t** walk_of_tile);
 

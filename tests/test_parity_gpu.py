@@ -532,6 +532,43 @@ def test_walk_order_changes_no_bit(depth, aa, P, scale, form):
         assert torch.equal(b["grads"][k], c["grads"][k]), k      # (and run to run: which workgroup takes which tile varies)
 
 
+@pytest.mark.parametrize("form", ["tile", "quad", "tile-mfma"])
+@pytest.mark.parametrize("depth,aa,P,scale", [(False, False, 6000, 0.8), (True, True, 3000, 2.5), (False, False, 40, 6.0)])
+def test_validity_flags_of_the_gradient_records_change_nothing(depth, aa, P, scale, form):
+    """Round 4: on frames of 2.5 M tile instances and more, an instance behind its tile's walk gets no (all-zero) gradient record
+    but a zero validity byte, and the projection backward reads the bytes of a Gaussian's slots - sixteen per load - before it
+    touches a record.  Forced on here (gsr_debug_set_flags_min_r(0)) for small scenes whose Gaussians have from one to well over
+    sixteen instances (big splats: the second flag chunk) and compared with the zero-record form (threshold 2^32 - 1): every
+    gradient equal (torch.equal: a sum that skips a +0.0 may come out as -0.0), in all three compositing-backward kernels."""
+    from diff_gaussian_rasterization import _C
+    lib = _C.lib()
+    raw = make_gaussians(P, 2, seed=431, scale_factor=scale)
+    cam = fibonacci_cameras(3, 208, 144, seed=433)[0]
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    gc, gd = upstream_grads(cam.image_height, cam.image_width, depth=depth)
+    old = {k: os.environ.get(k) for k in ("GSR_BWD_FORM", "GSR_BWD_REDUCE", "GSR_BWD_LPT")}
+    before = lib.gsr_debug_set_flags_min_r(-1)
+    try:
+        os.environ["GSR_BWD_FORM"] = form.split("-")[0]
+        os.environ["GSR_BWD_LPT"] = "1"
+        if form.endswith("mfma"):
+            os.environ["GSR_BWD_REDUCE"] = "mfma"
+        lib.gsr_debug_set_flags_min_r(0xFFFFFFFF)
+        a = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
+        lib.gsr_debug_set_flags_min_r(0)
+        b = run_hip(raw, cam, 2, bg, antialiasing=aa, gc=gc, gd=gd if depth else None)
+    finally:
+        lib.gsr_debug_set_flags_min_r(before)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert float(b["grads"]["means3D"].abs().sum()) > 0
+    for k in a["grads"]:
+        assert torch.equal(a["grads"][k], b["grads"][k]), (k, float((a["grads"][k] - b["grads"][k]).abs().max()))
+
+
 def test_matrix_pipe_reduction_primitive():
     """Round 4 (opt-in form, GSR_BWD_REDUCE=mfma; measured slower, kept as evidence): k_render_bwd_tile_mx takes an entry's ten sums over the tile's 256 pixels on the matrix pipe (v_mfma_f32_16x16x4_f32
     against the tile's separable pixel basis, csrc/render.hip).  The hook runs that very stage-1 / stage-2 / LDS slot / record code
