@@ -108,7 +108,13 @@ static int debug_sync(const gsr_settings* s, hipStream_t st, const char* stage, 
 // per-kernel profiling (HIP events on the launch stream)
 // ---------------------------------------------------------------------------------------------------
 int g_gsr_profile_on = 0;
-unsigned g_gsr_flags_min_r = GSR_FLAGS_MIN_R;     // frames with at least this many instances flag their gradient records (gsr_common.h)
+// frames with at least this many instances flag their gradient records (gsr_common.h); GSR_FLAGS_MIN_R in the environment of the
+// process sets the starting value (0 = always: how the seeded sweeps run their small scenes through the flagged form)
+static unsigned flags_min_r_from_env() {
+  const char* e = getenv("GSR_FLAGS_MIN_R");
+  return e && *e ? (unsigned)strtoul(e, nullptr, 10) : GSR_FLAGS_MIN_R;
+}
+unsigned g_gsr_flags_min_r = flags_min_r_from_env();
 namespace {
 struct Pending { const char* name; hipEvent_t a, b; };
 std::mutex g_prof_mu;
